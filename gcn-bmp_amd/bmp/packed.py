@@ -1,0 +1,313 @@
+"""Packed molecule batches: the HBM layout the HIP kernels work on.
+
+The reference batches molecules by zero-padding every molecule of a batch side
+to the side's max atom count A (``concat_mols``, train_ddi_modify.py:296) and
+carries a dense (mb, 4, A, A) adjacency that is ~99 % zeros.  Padded atoms are
+NOT masked anywhere (models/ggnn.py:340,603; nie_coattention.py:347-349), so
+results depend on A.  The packed layout reproduces those semantics exactly
+without doing the padded work:
+
+* rows -- every molecule contributes its real atoms plus ONE *virtual pad row*
+  (atom id 0, no bonds) whose multiplicity ``row_w`` = A - n stands for all of
+  its zero-padded positions (they share one trajectory: same embedding row,
+  message 0).  Real rows have ``row_w`` = 1.  Every sum over atoms in the
+  reference (readout, softmax denominators, attention-weighted sums) becomes a
+  ``row_w``-weighted sum.
+* tiles -- rows are laid out in tiles of R rows (R multiple of 32, default 128);
+  a molecule never straddles a tile, so all neighbour gathers are tile-local
+  (LDS-resident in the fused kernels).  Unused rows at a tile's end are *dead
+  rows* (``row_w`` = 0, id 0, no edges).  All row-indexed buffers are
+  (n_tiles*R, .) so GEMM kernels need no bounds checks.
+* bonds -- CSR over destination rows: ``csr_col`` = (src_row << 2) | bond_type,
+  ``csr_val`` = adjacency value (1.0; 1/deg after RelGCN's rescale_adj,
+  models/relgcn.py:20-28).  ``csrT_*`` is the transpose (by source row) used by
+  the backward pass; for the reference's symmetric adjacency it equals the CSR
+  but it is always built so asymmetric dense inputs stay exact.
+
+Index work here is integer-exact and is checked bit-for-bit against the dense
+form in tests/test_packed.py.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .synth import Molecule, NUM_EDGE_TYPE
+
+DEFAULT_R = 128
+
+
+def _ragged_arange(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """concatenate([arange(s, s+l) for s, l in zip(starts, lens)]) without a Python loop."""
+    lens = lens.astype(np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    excl = np.cumsum(lens) - lens
+    return np.repeat(starts.astype(np.int64) - excl, lens) + np.arange(total, dtype=np.int64)
+
+
+class MolStore:
+    """Flat per-molecule local CSR of a drug store (host, numpy).  Row space per
+    molecule: n real atoms followed by the virtual pad row."""
+
+    def __init__(self, mols: Sequence[Molecule]):
+        self.n_mols = len(mols)
+        self.n_atoms = np.array([m.n for m in mols], dtype=np.int64)
+        self.nrows = self.n_atoms + 1
+        self.row_off = np.cumsum(self.nrows) - self.nrows
+        self.atom_flat = np.zeros(int(self.nrows.sum()), dtype=np.int32)
+        e_dst, e_src, e_typ = [], [], []
+        self.nedges = np.zeros(self.n_mols, dtype=np.int64)
+        for k, m in enumerate(mols):
+            o = self.row_off[k]
+            self.atom_flat[o:o + m.n] = m.atoms
+            if len(m.bonds):
+                i, j, t = m.bonds[:, 0].astype(np.int64), m.bonds[:, 1].astype(np.int64), m.bonds[:, 2]
+                e_dst.append(np.concatenate((i, j)))          # local row ids
+                e_src.append(np.concatenate((j, i)))
+                e_typ.append(np.concatenate((t, t)))
+                self.nedges[k] = 2 * len(i)
+            else:
+                e_dst.append(np.zeros(0, np.int64)); e_src.append(np.zeros(0, np.int64))
+                e_typ.append(np.zeros(0, np.int32))
+        self.edge_off = np.cumsum(self.nedges) - self.nedges
+        self.e_dst = np.concatenate(e_dst).astype(np.int64)
+        self.e_src = np.concatenate(e_src).astype(np.int64)
+        self.e_typ = np.concatenate(e_typ).astype(np.int64)
+
+
+def _bin_pack(sizes: np.ndarray, R: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """First-fit-decreasing of item sizes into bins of capacity R.
+    Returns (bin index, offset inside bin) per item and the bin count."""
+    if len(sizes) and int(sizes.max()) > R:
+        raise ValueError(f"molecule with {int(sizes.max())} rows does not fit a tile of R={R}")
+    order = np.argsort(-sizes, kind="stable")
+    caps = np.full(len(sizes) + 1, R, dtype=np.int64)
+    nb = 0
+    bins = np.zeros(len(sizes), dtype=np.int64)
+    offs = np.zeros(len(sizes), dtype=np.int64)
+    for it in order:
+        s = int(sizes[it])
+        fit = caps[:nb] >= s
+        b = int(np.argmax(fit)) if nb and fit.any() else nb
+        if b == nb:
+            nb += 1
+        bins[it] = b
+        offs[it] = R - caps[b]
+        caps[b] -= s
+    return bins, offs, nb
+
+
+@dataclass
+class PackedMolBatch:
+    """Device-resident packed batch (see module docstring).  All index tensors int32."""
+    R: int
+    n_tiles: int
+    n_mols: int
+    atom_id: torch.Tensor          # (N,)
+    row_w: torch.Tensor            # (N,) float32
+    csr_ptr: torch.Tensor          # (N+1,)
+    csr_col: torch.Tensor          # (E,)  src_row<<2 | type
+    csr_val: torch.Tensor          # (E,) float32
+    csrT_ptr: torch.Tensor
+    csrT_col: torch.Tensor         # (E,)  dst_row<<2 | type
+    csrT_val: torch.Tensor
+    mol_row0: torch.Tensor         # (n_mols,)
+    mol_nrows: torch.Tensor        # (n_mols,)  real atoms + 1
+    side_tiles: Tuple[int, ...] = (0,)            # tile boundaries of the sides: (0, T1[, T1+T2])
+    side_mols: Tuple[int, ...] = (0,)             # molecule boundaries of the sides
+    dense_map: Optional[torch.Tensor] = None      # (n_mols, A) int64 row of every dense position (one side only)
+    dense_maps: Optional[List[torch.Tensor]] = None   # per side
+    n_real_atoms: int = 0
+    n_edges: int = 0
+    max_rows_per_mol: int = 0
+    _cache: dict = field(default_factory=dict, repr=False)
+
+    @property
+    def n_rows(self) -> int:
+        return self.n_tiles * self.R
+
+    @property
+    def device(self) -> torch.device:
+        return self.atom_id.device
+
+    def with_edge_vals(self, csr_val: torch.Tensor, csrT_val: torch.Tensor) -> "PackedMolBatch":
+        import dataclasses
+        return dataclasses.replace(self, csr_val=csr_val, csrT_val=csrT_val, _cache={})
+
+    def to_dense(self, rows: torch.Tensor, side: int = 0) -> torch.Tensor:
+        """Expand a (N, c) row tensor to the reference's dense (mb, A, c) layout."""
+        dm = self.dense_maps[side] if self.dense_maps is not None else self.dense_map
+        if dm is None:
+            raise ValueError("this batch has no dense position map")
+        return rows[dm]
+
+
+def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
+              e_dst: np.ndarray, e_src: np.ndarray, e_typ: np.ndarray, e_val: np.ndarray,
+              side_of_inst: np.ndarray, n_sides: int, R: int, device,
+              dense_maps_flat: Optional[List[np.ndarray]] = None) -> PackedMolBatch:
+    """Common placement step: bin-pack instances into tiles (per side), remap rows
+    and edges, build CSR + transposed CSR, upload."""
+    I = len(inst_nrows)
+    flat_off = np.cumsum(inst_nrows) - inst_nrows
+    inst_row0 = np.zeros(I, dtype=np.int64)
+    side_tiles = [0]
+    side_mols = [0]
+    tile0 = 0
+    for s in range(n_sides):
+        sel = np.nonzero(side_of_inst == s)[0]
+        bins, offs, nb = _bin_pack(inst_nrows[sel], R)
+        inst_row0[sel] = (tile0 + bins) * R + offs
+        tile0 += nb
+        side_tiles.append(tile0)
+        side_mols.append(side_mols[-1] + len(sel))
+    n_tiles = tile0
+    N = n_tiles * R
+    rowmap = _ragged_arange(inst_row0, inst_nrows)              # flat row -> packed row
+    atom_id = np.zeros(N, dtype=np.int32)
+    row_w = np.zeros(N, dtype=np.float32)
+    atom_id[rowmap] = flat_atom
+    row_w[rowmap] = flat_w
+    dst = rowmap[e_dst] if len(e_dst) else np.zeros(0, np.int64)
+    src = rowmap[e_src] if len(e_src) else np.zeros(0, np.int64)
+
+    def build(major: np.ndarray, minor: np.ndarray):
+        order = np.lexsort((e_typ, minor, major))
+        ptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(np.bincount(major, minlength=N), out=ptr[1:])
+        col = ((minor[order] << 2) | e_typ[order]).astype(np.int32)
+        return ptr.astype(np.int32), col, e_val[order].astype(np.float32)
+
+    csr_ptr, csr_col, csr_val = build(dst, src)
+    csrT_ptr, csrT_col, csrT_val = build(src, dst)
+
+    ints = [atom_id, csr_ptr, csr_col, csrT_ptr, csrT_col, inst_row0.astype(np.int32), inst_nrows.astype(np.int32)]
+    flts = [row_w, csr_val, csrT_val]
+    ibuf = torch.from_numpy(np.concatenate(ints)).to(device)
+    fbuf = torch.from_numpy(np.concatenate(flts)).to(device)
+    iv, o = [], 0
+    for a in ints:
+        iv.append(ibuf[o:o + len(a)]); o += len(a)
+    fv, o = [], 0
+    for a in flts:
+        fv.append(fbuf[o:o + len(a)]); o += len(a)
+    dmaps = None
+    if dense_maps_flat is not None:
+        dmaps = [torch.from_numpy(rowmap[dm]).to(device) for dm in dense_maps_flat]
+    return PackedMolBatch(
+        R=R, n_tiles=n_tiles, n_mols=I,
+        atom_id=iv[0], row_w=fv[0],
+        csr_ptr=iv[1], csr_col=iv[2], csr_val=fv[1],
+        csrT_ptr=iv[3], csrT_col=iv[4], csrT_val=fv[2],
+        mol_row0=iv[5], mol_nrows=iv[6],
+        side_tiles=tuple(side_tiles), side_mols=tuple(side_mols),
+        dense_map=dmaps[0] if dmaps is not None and len(dmaps) == 1 else None,
+        dense_maps=dmaps,
+        n_real_atoms=int((flat_w == 1).sum()), n_edges=int(len(e_dst)),
+        max_rows_per_mol=int(inst_nrows.max()) if I else 0,
+    )
+
+
+def pack_from_store(store: MolStore, sides: Sequence[np.ndarray], R: int = DEFAULT_R, device="cpu",
+                    with_dense_map: bool = False, pad_to: Optional[Sequence[int]] = None) -> PackedMolBatch:
+    """Pack molecule instances ``sides[s][b]`` (indices into the store).  Each side is
+    zero-padded to its own max atom count (concat_mols pads every field of the
+    batch independently), or to ``pad_to[s]`` when given."""
+    mids = np.concatenate([np.asarray(s, dtype=np.int64) for s in sides])
+    side_of = np.concatenate([np.full(len(s), k, dtype=np.int64) for k, s in enumerate(sides)])
+    n = store.n_atoms[mids]
+    A = np.zeros(len(sides), dtype=np.int64)
+    for k in range(len(sides)):
+        A[k] = int(n[side_of == k].max()) if pad_to is None else int(pad_to[k])
+    inst_nrows = n + 1
+    flat_off = np.cumsum(inst_nrows) - inst_nrows
+    src_rows = _ragged_arange(store.row_off[mids], inst_nrows)
+    flat_atom = store.atom_flat[src_rows]
+    flat_w = np.ones(len(flat_atom), dtype=np.float32)
+    flat_w[flat_off + n] = (A[side_of] - n).astype(np.float32)      # virtual pad rows
+    ne = store.nedges[mids]
+    eidx = _ragged_arange(store.edge_off[mids], ne)
+    eshift = np.repeat(flat_off, ne)
+    e_dst = store.e_dst[eidx] + eshift
+    e_src = store.e_src[eidx] + eshift
+    e_typ = store.e_typ[eidx]
+    e_val = np.ones(len(eidx), dtype=np.float32)
+    dmf = None
+    if with_dense_map:
+        dmf = []
+        for k in range(len(sides)):
+            sel = np.nonzero(side_of == k)[0]
+            a = np.arange(A[k])[None, :]
+            dm = np.where(a < n[sel][:, None], flat_off[sel][:, None] + a, (flat_off[sel] + n[sel])[:, None])
+            dmf.append(dm)
+    return _assemble(inst_nrows, flat_atom, flat_w, e_dst, e_src, e_typ, e_val, side_of, len(sides), R, device, dmf)
+
+
+def pack_from_dense(atom_arrays: Sequence[np.ndarray], adjs: Sequence[np.ndarray], R: int = DEFAULT_R,
+                    device="cpu") -> PackedMolBatch:
+    """Pack the reference's dense batch form: per side ``atom_array`` (mb, A) int32 and
+    ``adj`` (mb, 4, A, A) float32.  A position is merged into the
+    molecule's virtual pad row iff its atom id is 0 and it has no incoming bond --
+    exactly the positions that follow the shared pad trajectory.  Integer-exact."""
+    inst_nrows_l, flat_atom_l, flat_w_l = [], [], []
+    e_dst_l, e_src_l, e_typ_l, e_val_l, side_l, dmf = [], [], [], [], [], []
+    flat_base = 0
+    for k, (atoms, adj) in enumerate(zip(atom_arrays, adjs)):
+        atoms = np.asarray(atoms)
+        adj = np.asarray(adj, dtype=np.float32)
+        mb, A = atoms.shape
+        if adj.shape != (mb, NUM_EDGE_TYPE, A, A):
+            raise ValueError(f"adj shape {adj.shape} does not match atoms {atoms.shape}")
+        nzb, nze, nzi, nzj = np.nonzero(adj)
+        indeg = np.zeros((mb, A), dtype=np.int64)
+        np.add.at(indeg, (nzb, nzi), 1)
+        padlike = (atoms == 0) & (indeg == 0)
+        real = ~padlike
+        n = real.sum(axis=1).astype(np.int64)
+        local = np.cumsum(real, axis=1) - 1
+        nrows = n + 1
+        off = flat_base + np.cumsum(nrows) - nrows
+        dm = np.where(real, off[:, None] + local, (off + n)[:, None])          # (mb, A) flat row
+        fa = np.zeros(int(nrows.sum()), dtype=np.int32)
+        fw = np.ones(int(nrows.sum()), dtype=np.float32)
+        fa[dm[real] - flat_base] = atoms[real]
+        fw[off + n - flat_base] = padlike.sum(axis=1).astype(np.float32)
+        inst_nrows_l.append(nrows); flat_atom_l.append(fa); flat_w_l.append(fw)
+        e_dst_l.append(dm[nzb, nzi]); e_src_l.append(dm[nzb, nzj]); e_typ_l.append(nze.astype(np.int64))
+        e_val_l.append(adj[nzb, nze, nzi, nzj])
+        side_l.append(np.full(mb, k, dtype=np.int64))
+        dmf.append(dm)
+        flat_base += int(nrows.sum())
+    return _assemble(np.concatenate(inst_nrows_l), np.concatenate(flat_atom_l), np.concatenate(flat_w_l),
+                     np.concatenate(e_dst_l), np.concatenate(e_src_l), np.concatenate(e_typ_l),
+                     np.concatenate(e_val_l), np.concatenate(side_l), len(atom_arrays), R, device, dmf)
+
+
+def unpack_to_dense(pb: PackedMolBatch, side: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Inverse of pack_from_dense for one side (host, for tests): rebuild
+    (atoms (mb, A) int32, adj (mb, 4, A, A) float32) from the packed arrays."""
+    dm = pb.dense_maps[side].cpu().numpy()
+    mb, A = dm.shape
+    atom_id = pb.atom_id.cpu().numpy()
+    atoms = atom_id[dm].astype(np.int32)
+    adj = np.zeros((mb, NUM_EDGE_TYPE, A, A), dtype=np.float32)
+    ptr = pb.csr_ptr.cpu().numpy().astype(np.int64)
+    col = pb.csr_col.cpu().numpy().astype(np.int64)
+    val = pb.csr_val.cpu().numpy()
+    N = pb.n_rows
+    row_of_edge = np.repeat(np.arange(N), np.diff(ptr))
+    # first dense position of every packed row (virtual rows map to their first pad position)
+    pos_b = np.full(N, -1, dtype=np.int64)
+    pos_a = np.full(N, -1, dtype=np.int64)
+    bb, aa = np.meshgrid(np.arange(mb), np.arange(A), indexing="ij")
+    pos_b[dm[::-1, ::-1].ravel()] = bb[::-1, ::-1].ravel()
+    pos_a[dm[::-1, ::-1].ravel()] = aa[::-1, ::-1].ravel()
+    src = col >> 2
+    keep = (pos_b[row_of_edge] >= 0) & (pos_b[src] >= 0)
+    adj[pos_b[row_of_edge][keep], (col & 3)[keep], pos_a[row_of_edge][keep], pos_a[src][keep]] = val[keep]
+    return atoms, adj
