@@ -1,0 +1,107 @@
+"""ctypes binding of libbmp_hip.so (the C ABI declared in include/bmp.h).
+
+The HIP library is the product path: there is no CPU or PyTorch fallback.  A missing or
+unloadable library raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbmp_hip.so")
+
+_P, _I, _Z = c_void_p, c_int, c_size_t
+
+# name -> (restype, argtypes); mirrors include/bmp.h declaration by declaration
+SIGNATURES = {
+    "bmp_version": (_I, []),
+    "bmp_tile_rows": (_I, []),
+    "bmp_embed_fwd": (_I, [_P, _P, _I, _I, _P, _P]),
+    "bmp_embed_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "bmp_msg_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    "bmp_msg_bwd_ws_floats": (_Z, [_I, _I, _I]),
+    "bmp_msg_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_gru_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "bmp_gru_bwd_ws_floats": (_Z, [_I, _I]),
+    "bmp_gru_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_readout_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "bmp_readout_bwd_ws_floats": (_Z, [_I, _I, _I, _I]),
+    "bmp_readout_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_linear_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "bmp_wgrad_ws_floats_c": (_Z, [_I, _I, _I]),
+    "bmp_linear_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+_hip = None
+
+
+class BmpLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the HIP library; fail loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BmpLibraryError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no fallback path.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:                                  # pragma: no cover
+            raise BmpLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise BmpLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _hip_error_string(code: int) -> str:
+    global _hip
+    try:
+        if _hip is None:
+            _hip = ctypes.CDLL("libamdhip64.so")
+            _hip.hipGetErrorString.restype = ctypes.c_char_p
+            _hip.hipGetErrorString.argtypes = [c_int]
+        return _hip.hipGetErrorString(code).decode()
+    except Exception:                                         # pragma: no cover
+        return "?"
+
+
+def check(rc: int, name: str) -> None:
+    if rc == 0:
+        return
+    if rc < -1000:
+        raise ValueError(f"{name}: argument check failed at csrc line {-(rc + 1000)}")
+    raise RuntimeError(f"{name}: HIP error {rc} ({_hip_error_string(rc)})")
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_rows(t: torch.Tensor, name: str, cols: int | None = None) -> torch.Tensor:
+    """Shape/dtype/contiguity checks before a launch (ValueError, like the reference's
+    option checks, e.g. models/ggnn.py:250)."""
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a float32 CUDA(HIP) tensor")
+    if t.dim() != 2 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous 2-d tensor, got shape {tuple(t.shape)}")
+    if cols is not None and t.shape[1] != cols:
+        raise ValueError(f"{name}: expected {cols} columns, got {t.shape[1]}")
+    return t

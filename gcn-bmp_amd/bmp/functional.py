@@ -1,0 +1,257 @@
+"""torch.autograd.Functions over the C ABI: one Function per reference operator.
+
+Every Function's forward/backward is a 1:1 call into libbmp_hip (include/bmp.h).  torch is
+used for device memory, the stream and the autograd graph only; weight layout changes
+(reference [out x in] -> kernel K-major) are differentiable torch views done by the callers
+in bmp/ggnn.py etc., so parameter gradients come back in the reference layout.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, ptr, stream, require_rows
+from .packed import PackedMolBatch
+
+ACT = {"identity": 0, None: 0, "sigmoid": 1, "tanh": 2, "relu": 3}
+
+
+def _ws(nfloats: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nfloats), 4), dtype=torch.float32, device=device)
+
+
+def _check_pb(pb: PackedMolBatch, x: torch.Tensor) -> None:
+    L = _lib.lib()
+    if pb.R != L.bmp_tile_rows():
+        raise ValueError(f"packed batch tile size R={pb.R} != library tile rows {L.bmp_tile_rows()}")
+    if x.shape[0] != pb.n_rows:
+        raise ValueError(f"row tensor has {x.shape[0]} rows, packed batch has {pb.n_rows}")
+
+
+class EmbedFn(Function):
+    """EmbedAtomID (models/ggnn.py:85,603)."""
+
+    @staticmethod
+    def forward(ctx, W, ids):
+        L = _lib.lib()
+        if W.dtype != torch.float32 or not W.is_cuda or not W.is_contiguous():
+            raise ValueError("embed: W must be a contiguous float32 CUDA tensor")
+        if ids.dtype != torch.int32 or not ids.is_contiguous():
+            raise ValueError("embed: ids must be contiguous int32")
+        V, d = W.shape
+        N = ids.numel()
+        out = torch.empty(N, d, dtype=torch.float32, device=W.device)
+        check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, ptr(out), stream()), "bmp_embed_fwd")
+        ctx.save_for_backward(ids)
+        ctx.V = V
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        (ids,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, d = dout.shape
+        dW = torch.zeros(ctx.V, d, dtype=torch.float32, device=dout.device)
+        check(L.bmp_embed_bwd(ptr(ids), ptr(dout), N, d, ctx.V, ptr(dW), stream()), "bmp_embed_bwd")
+        return dW, None
+
+
+class MsgFn(Function):
+    """Message / RelGCN layer (models/ggnn.py:215-243; models/update/relgcn_update.py:24-44).
+    WT [4*d_in x d_out], bE [4 x d_out], optional self connection WsT [d_in x d_out], bs [d_out]."""
+
+    @staticmethod
+    def forward(ctx, x, WT, bE, WsT, bs, pb, act):
+        L = _lib.lib()
+        require_rows(x, "msg: x")
+        _check_pb(pb, x)
+        d_in = x.shape[1]
+        d_out = WT.shape[1]
+        if WT.shape[0] != 4 * d_in or tuple(bE.shape) != (4, d_out):
+            raise ValueError("msg: weight shapes do not match x")
+        WT = WT.contiguous(); bE = bE.contiguous()
+        WsT = None if WsT is None else WsT.contiguous()
+        bs = None if bs is None else bs.contiguous()
+        N = x.shape[0]
+        agg = torch.empty(N, 4 * d_in, dtype=torch.float32, device=x.device)
+        wdeg = torch.empty(N, 4, dtype=torch.float32, device=x.device)
+        out = torch.empty(N, d_out, dtype=torch.float32, device=x.device)
+        check(L.bmp_msg_fwd(ptr(x), d_in, pb.n_tiles, d_in, d_out, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+                            ptr(WT), ptr(bE), ptr(WsT), ptr(bs), act, ptr(agg), ptr(wdeg), ptr(out), d_out, stream()),
+              "bmp_msg_fwd")
+        ctx.save_for_backward(x, WT, WsT if WsT is not None else torch.empty(0), agg, wdeg, out)
+        ctx.pb, ctx.act, ctx.has_self, ctx.has_bs = pb, act, WsT is not None, bs is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, WT, WsT, agg, wdeg, out = ctx.saved_tensors
+        pb = ctx.pb
+        dout = dout.contiguous()
+        N, d_out = dout.shape
+        d_in = x.shape[1]
+        dev = x.device
+        Wnat = WT.t().contiguous()
+        Ws = WsT.t().contiguous() if ctx.has_self else None
+        dx = torch.empty(N, d_in, dtype=torch.float32, device=dev)
+        dWT = torch.empty_like(WT)
+        dbE = torch.empty(4, d_out, dtype=torch.float32, device=dev)
+        dWsT = torch.empty(d_in, d_out, dtype=torch.float32, device=dev) if ctx.has_self else None
+        dbs = torch.empty(d_out, dtype=torch.float32, device=dev) if ctx.has_self else None
+        nws = L.bmp_msg_bwd_ws_floats(pb.n_tiles, d_in, d_out)
+        ws = _ws(nws, dev)
+        check(L.bmp_msg_bwd(ptr(dout), d_out, ptr(out), d_out, ctx.act, ptr(x), d_in, pb.n_tiles, d_in, d_out,
+                            ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(Ws), ptr(agg), ptr(wdeg),
+                            ptr(dx), ptr(dWT), ptr(dbE), ptr(dWsT), ptr(dbs), ptr(ws), nws, stream()), "bmp_msg_bwd")
+        return dx, dWT, dbE, dWsT, (dbs if ctx.has_bs else None), None, None
+
+
+class GRUFn(Function):
+    """GRU node update (chainer StatefulGRU at models/ggnn.py:132,254-262).
+    AT [2d x 3d], UcT [d x d], b [3d] in the folded kernel layout (see bmp/ggnn.py)."""
+
+    @staticmethod
+    def forward(ctx, h, m, AT, UcT, b, pb, first):
+        L = _lib.lib()
+        require_rows(h, "gru: h")
+        require_rows(m, "gru: m", h.shape[1])
+        _check_pb(pb, h)
+        N, d = h.shape
+        if tuple(AT.shape) != (2 * d, 3 * d) or tuple(UcT.shape) != (d, d) or tuple(b.shape) != (3 * d,):
+            raise ValueError("gru: weight shapes do not match h")
+        AT = AT.contiguous(); UcT = UcT.contiguous(); b = b.contiguous()
+        rz = torch.empty(N, 2 * d, dtype=torch.float32, device=h.device)
+        c = torch.empty(N, d, dtype=torch.float32, device=h.device)
+        hout = torch.empty(N, d, dtype=torch.float32, device=h.device)
+        check(L.bmp_gru_fwd(ptr(h), ptr(m), pb.n_tiles, d, int(first), ptr(AT), ptr(UcT), ptr(b), ptr(rz), ptr(c),
+                            ptr(hout), stream()), "bmp_gru_fwd")
+        ctx.save_for_backward(h, m, AT, UcT, rz, c)
+        ctx.pb, ctx.first = pb, int(first)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dhout):
+        L = _lib.lib()
+        h, m, AT, UcT, rz, c = ctx.saved_tensors
+        pb = ctx.pb
+        dhout = dhout.contiguous()
+        N, d = h.shape
+        dev = h.device
+        A = AT.t().contiguous()
+        Uc = UcT.t().contiguous()
+        dh = torch.empty_like(h); dm = torch.empty_like(m)
+        dAT = torch.empty_like(AT); dUcT = torch.empty_like(UcT)
+        db = torch.empty(3 * d, dtype=torch.float32, device=dev)
+        nws = L.bmp_gru_bwd_ws_floats(pb.n_tiles, d)
+        ws = _ws(nws, dev)
+        check(L.bmp_gru_bwd(ptr(dhout), ptr(h), ptr(m), ptr(rz), ptr(c), pb.n_tiles, d, ctx.first, ptr(A), ptr(Uc),
+                            ptr(dh), ptr(dm), ptr(dAT), ptr(dUcT), ptr(db), ptr(ws), nws, stream()), "bmp_gru_bwd")
+        return dh, dm, dAT, dUcT, db, None, None
+
+
+class ReadoutFn(Function):
+    """Gated-sum readout (models/ggnn.py:333-341; models/readout/ggnn_readout.py:42-57).
+    WT [(d+d0) x 2o] cols [i|j]; b [2o] or None; h0 may be None."""
+
+    @staticmethod
+    def forward(ctx, h, h0, WT, b, pb, act_j):
+        L = _lib.lib()
+        require_rows(h, "readout: h")
+        _check_pb(pb, h)
+        if h0 is not None:
+            require_rows(h0, "readout: h0")
+        N, d = h.shape
+        d0 = 0 if h0 is None else h0.shape[1]
+        o = WT.shape[1] // 2
+        if WT.shape[0] != d + d0 or WT.shape[1] != 2 * o:
+            raise ValueError("readout: weight shape does not match [h, h0]")
+        WT = WT.contiguous()
+        b = None if b is None else b.contiguous()
+        ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+        g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
+        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(b), act_j, ptr(pb.row_w),
+                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()),
+              "bmp_readout_fwd")
+        ctx.save_for_backward(h, h0 if h0 is not None else torch.empty(0), WT, ij)
+        ctx.pb, ctx.act_j, ctx.has_h0, ctx.has_b, ctx.o = pb, act_j, h0 is not None, b is not None, o
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        L = _lib.lib()
+        h, h0, WT, ij = ctx.saved_tensors
+        pb, o = ctx.pb, ctx.o
+        dg = dg.contiguous()
+        N, d = h.shape
+        dev = h.device
+        h0 = h0 if ctx.has_h0 else None
+        d0 = h0.shape[1] if ctx.has_h0 else 0
+        Wnat = WT.t().contiguous()
+        dh = torch.empty_like(h)
+        dh0 = torch.empty_like(h0) if ctx.has_h0 else None
+        dWT = torch.empty_like(WT)
+        db = torch.empty(2 * o, dtype=torch.float32, device=dev) if ctx.has_b else None
+        nws = L.bmp_readout_bwd_ws_floats(pb.n_tiles, d, d0, o)
+        ws = _ws(nws, dev)
+        check(L.bmp_readout_bwd(ptr(dg), ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(Wnat), ptr(ij), ctx.act_j,
+                                ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0), ptr(dWT),
+                                ptr(db), ptr(ws), nws, stream()), "bmp_readout_bwd")
+        return dh, dh0, dWT, db, None, None
+
+
+class LinearRowsFn(Function):
+    """GraphLinear on packed rows: Y = act(X . WT + b).  X [N x K] with N a multiple of the
+    tile size; WT [K x Nout]."""
+
+    @staticmethod
+    def forward(ctx, X, WT, b, act):
+        L = _lib.lib()
+        require_rows(X, "linear: X")
+        N, K = X.shape
+        R = L.bmp_tile_rows()
+        if N % R or K % 8:
+            raise ValueError(f"linear: rows must be a multiple of {R} and K a multiple of 8")
+        WT = WT.contiguous()
+        b = None if b is None else b.contiguous()
+        Nout = WT.shape[1]
+        Y = torch.empty(N, Nout, dtype=torch.float32, device=X.device)
+        check(L.bmp_linear_fwd(ptr(X), K, N // R, K, Nout, ptr(WT), Nout, ptr(b), act, ptr(Y), Nout, stream()),
+              "bmp_linear_fwd")
+        ctx.save_for_backward(X, WT, Y)
+        ctx.act, ctx.has_b = act, b is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = _lib.lib()
+        X, WT, Y = ctx.saved_tensors
+        N, K = X.shape
+        Nout = WT.shape[1]
+        R = L.bmp_tile_rows()
+        dY = dY.contiguous()
+        if ctx.act == 1:
+            dY = dY * Y * (1 - Y)
+        elif ctx.act == 2:
+            dY = dY * (1 - Y * Y)
+        elif ctx.act == 3:
+            dY = dY * (Y > 0)
+        # dX = dY . W  (needs Nout % 8 == 0: pad the K axis of this GEMM with zeros otherwise)
+        Wn = WT.t().contiguous()                                   # [Nout x K]
+        dYp = dY
+        if Nout % 8:
+            pad = 8 - Nout % 8
+            dYp = torch.nn.functional.pad(dY, (0, pad)).contiguous()
+            Wn = torch.nn.functional.pad(Wn, (0, 0, 0, pad)).contiguous()
+        dX = torch.empty_like(X)
+        check(L.bmp_linear_fwd(ptr(dYp), dYp.shape[1], N // R, dYp.shape[1], K, ptr(Wn), K, None, 0, ptr(dX), K, stream()),
+              "bmp_linear_fwd(dX)")
+        dWT = torch.empty_like(WT)
+        db = torch.empty(Nout, dtype=torch.float32, device=X.device) if ctx.has_b else None
+        nws = L.bmp_wgrad_ws_floats_c(N, K, Nout)
+        ws = _ws(nws, X.device)
+        check(L.bmp_linear_wgrad(ptr(X), K, ptr(dY), Nout, N, K, Nout, ptr(dWT), ptr(db), ptr(ws), nws, stream()),
+              "bmp_linear_wgrad")
+        return dX, dWT, db, None

@@ -1,0 +1,189 @@
+"""GGNN encoder with the reference's constructor and call signatures.
+
+Mirrors ``models.ggnn.GGNN`` (models/ggnn.py:19-654) and ``models.ggnn_att.GGNN``
+(models/ggnn_att.py:39-664, which adds ``self.atoms`` / ``get_atom_array()``) on the default
+path: message_function='matrix_multiply', readout_function='graph_level', no attention, no
+layer aggregator, no context BiLSTM, no batch normalisation, no dropout.  Any other option
+raises NotImplementedError (they are research ablations outside SURVEY.md section 8).
+
+Parameter names and shapes follow the reference link tree (embed.W, message_layers.{i}.W/b,
+update_layer.{W_r,W_z,W,U_r,U_z,U}.W/b, i_layers.{k}.W/b, j_layers.{k}.W/b) so a Chainer
+snapshot maps key by key.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import functional as Fn
+from .packed import PackedMolBatch, pack_from_dense
+
+MAX_ATOMIC_NUM = 117      # chainer_chemistry.config.MAX_ATOMIC_NUM (models/ggnn.py:14)
+NUM_EDGE_TYPE = 4         # models/ggnn.py:37
+
+
+class Linear(nn.Module):
+    """Parameter holder with Chainer's Linear attribute names (W [out x in], b [out]) and
+    default initialisers (W ~ LeCunNormal, b = 0)."""
+
+    def __init__(self, in_size: int, out_size: int, nobias: bool = False):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(out_size, in_size) / math.sqrt(in_size))
+        self.b = None if nobias else nn.Parameter(torch.zeros(out_size))
+        self.in_size, self.out_size = in_size, out_size
+
+
+class EmbedID(nn.Module):
+    """chainer EmbedID / EmbedAtomID: W [in_size x out_size] ~ N(0, 1), no ignore label."""
+
+    def __init__(self, out_size: int, in_size: int = MAX_ATOMIC_NUM):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(in_size, out_size))
+
+
+class GRU(nn.Module):
+    """Parameters of chainer.links.GRU(2d, d) (StatefulGRU): W_r, W_z, W [d x 2d]; U_r, U_z, U [d x d]."""
+
+    def __init__(self, in_size: int, out_size: int):
+        super().__init__()
+        self.W_r = Linear(in_size, out_size); self.U_r = Linear(out_size, out_size)
+        self.W_z = Linear(in_size, out_size); self.U_z = Linear(out_size, out_size)
+        self.W = Linear(in_size, out_size); self.U = Linear(out_size, out_size)
+
+    def kernel_weights(self, first: bool):
+        """(AT [2d x 3d], UcT [d x d], b [3d]) in the layout of bmp_gru_fwd.  For later calls the
+        state terms are folded into the h-part (the GRU state equals h without dropout):
+        W_r x + U_r s = (W_r[:, :d] + U_r) h + W_r[:, d:] m  (SURVEY.md A.2)."""
+        d = self.U.W.shape[0]
+        A = torch.cat((self.W_r.W, self.W_z.W, self.W.W), dim=0)               # [3d x 2d]
+        if first:
+            b = torch.cat((self.W_r.b, self.W_z.b, self.W.b))
+        else:
+            fold = torch.cat((self.U_r.W, self.U_z.W, torch.zeros_like(self.U.W)), dim=0)   # [3d x d]
+            A = A + torch.cat((fold, torch.zeros_like(fold)), dim=1)
+            b = torch.cat((self.W_r.b + self.U_r.b, self.W_z.b + self.U_z.b, self.W.b + self.U.b))
+        return A.t().contiguous(), self.U.W.t().contiguous(), b
+
+
+def message_kernel_weights(lin: Linear):
+    """Reference GraphLinear(d_in, 4*d_out) with output feature k = 4*c + e
+    (models/ggnn.py:223-224) -> WT [4*d_in x d_out] (row e*d_in + k, col c), bE [4 x d_out]."""
+    o4, d_in = lin.W.shape
+    d_out = o4 // NUM_EDGE_TYPE
+    WT = lin.W.view(d_out, NUM_EDGE_TYPE, d_in).permute(1, 2, 0).reshape(NUM_EDGE_TYPE * d_in, d_out)
+    bE = lin.b.view(d_out, NUM_EDGE_TYPE).t() if lin.b is not None else torch.zeros(NUM_EDGE_TYPE, d_out, device=lin.W.device)
+    return WT.contiguous(), bE.contiguous()
+
+
+class PackedAtoms:
+    """What ``get_atom_array()`` hands to the co-attention: the per-row atom states of a
+    packed batch.  ``dense()`` expands to the reference's (mb, A, hidden_dim) array."""
+
+    def __init__(self, rows: torch.Tensor, pb: PackedMolBatch, side: Optional[int] = None):
+        self.rows, self.pb, self.side = rows, pb, side
+
+    def dense(self, side: Optional[int] = None) -> torch.Tensor:
+        return self.pb.to_dense(self.rows, self.side if side is None else side)
+
+
+def as_packed(atom_array, adj, device) -> PackedMolBatch:
+    """Accept the reference's dense batch (atom_array (mb, A) int32, adj (mb, 4, A, A) float32,
+    numpy or torch) or an already packed batch in the first slot."""
+    if isinstance(atom_array, PackedMolBatch):
+        return atom_array
+    a = atom_array.detach().cpu().numpy() if isinstance(atom_array, torch.Tensor) else np.asarray(atom_array)
+    j = adj.detach().cpu().numpy() if isinstance(adj, torch.Tensor) else np.asarray(adj)
+    if a.dtype.kind not in "iu":
+        raise NotImplementedError("float atom features (embedding bypass, models/ggnn.py:604-605) are not supported")
+    return pack_from_dense([a.astype(np.int32)], [j.astype(np.float32)], device=device)
+
+
+class GGNN(nn.Module):
+    NUM_EDGE_TYPE = NUM_EDGE_TYPE
+
+    def __init__(self, out_dim, hidden_dim=16, n_layers=4, n_atom_types=MAX_ATOMIC_NUM, concat_hidden=False,
+                 layer_aggregator=None, dropout_rate=0.0, batch_normalization=False, weight_tying=True,
+                 use_attention=False, update_attention=False, attention_tying=True,
+                 context=False, context_layers=1, context_dropout=0.,
+                 message_function='matrix_multiply', edge_hidden_dim=16,
+                 readout_function='graph_level', num_timesteps=3,
+                 num_output_hidden_layers=0, output_hidden_dim=16, output_activation=None,
+                 output_atoms=False):
+        super().__init__()
+        unsupported = dict(layer_aggregator=layer_aggregator, batch_normalization=batch_normalization,
+                           use_attention=use_attention, update_attention=update_attention, context=context)
+        for k, v in unsupported.items():
+            if v:
+                raise NotImplementedError(f"GGNN option {k}={v!r} is outside the MI355X hot path (SURVEY.md 2.1 #1)")
+        if dropout_rate != 0.0:
+            raise NotImplementedError("dropout_rate != 0 is not supported")
+        if message_function != 'matrix_multiply':
+            if message_function == 'edge_network':
+                raise NotImplementedError("message_function='edge_network' is not supported")
+            raise ValueError('There is no such message function named {}'.format(message_function))  # models/ggnn.py:250
+        if readout_function != 'graph_level':
+            raise NotImplementedError("readout_function='set2vec' is not supported")
+        if hidden_dim % 8:
+            raise ValueError("hidden_dim must be a multiple of 8 for the MFMA kernels")
+        if out_dim % 4:
+            raise ValueError("out_dim must be a multiple of 4")
+        self.out_dim, self.hidden_dim, self.n_layers = out_dim, hidden_dim, n_layers
+        self.concat_hidden, self.weight_tying = concat_hidden, weight_tying
+        self.n_readout_layer = n_layers if concat_hidden else 1
+        self.n_message_layer = 1 if weight_tying else n_layers
+        self.embed = EmbedID(out_size=hidden_dim, in_size=n_atom_types)
+        self.message_layers = nn.ModuleList(
+            [Linear(hidden_dim, NUM_EDGE_TYPE * hidden_dim) for _ in range(self.n_message_layer)])
+        self.update_layer = GRU(2 * hidden_dim, hidden_dim)
+        self.i_layers = nn.ModuleList([Linear(2 * hidden_dim, out_dim) for _ in range(self.n_readout_layer)])
+        self.j_layers = nn.ModuleList([Linear(hidden_dim, out_dim) for _ in range(self.n_readout_layer)])
+        self.atoms = None
+
+    # models/ggnn.py:333-341: i sees [h, h0], j sees h only -> j's h0 rows are zero in the kernel layout
+    def _readout_weights(self, k: int):
+        i, j = self.i_layers[k], self.j_layers[k]
+        d = self.hidden_dim
+        WT = torch.cat((i.W.t(), torch.cat((j.W.t(), torch.zeros(d, self.out_dim, device=j.W.device)), dim=0)), dim=1)
+        return WT.contiguous(), torch.cat((i.b, j.b))
+
+    def readout(self, h, h0, pb, step=0):
+        k = step if self.concat_hidden else 0
+        WT, b = self._readout_weights(k)
+        return Fn.ReadoutFn.apply(h, h0, WT, b, pb, Fn.ACT["identity"])
+
+    def forward(self, atom_array, adj=None):
+        """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``
+        (mb, 4, A, A), or a PackedMolBatch (then ``adj`` is ignored).  Returns (n_mols, out_dim)
+        [(n_mols, n_layers*out_dim) with concat_hidden]."""
+        dev = self.embed.W.device
+        pb = as_packed(atom_array, adj, dev)
+        h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)                 # :603
+        h0 = h                                                          # :612
+        later = None
+        g_list = []
+        for step in range(self.n_layers):                               # :616
+            li = 0 if self.weight_tying else step                       # :220
+            WT, bE = message_kernel_weights(self.message_layers[li])
+            m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
+            if step == 0:
+                AT, UcT, b = self.update_layer.kernel_weights(first=True)
+            else:
+                if later is None:
+                    later = self.update_layer.kernel_weights(first=False)
+                AT, UcT, b = later
+            h = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, step == 0)        # :254-262, state reset at :599
+            if self.concat_hidden:
+                g_list.append(self.readout(h, h0, pb, step))
+        self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)     # models/ggnn_att.py:651
+        if self.concat_hidden:
+            return torch.cat(g_list, dim=1)
+        return self.readout(h, h0, pb, 0)
+
+    def get_atom_array(self):
+        """models/ggnn_att.py:662-664.  Returns a PackedAtoms; ``.dense()`` gives (mb, A, hidden_dim)."""
+        assert self.atoms is not None
+        return self.atoms

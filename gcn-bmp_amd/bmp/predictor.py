@@ -1,0 +1,90 @@
+"""``GraphConvPredictorForPair`` -- the pair glue the reference re-declares in every script
+(no co-attention: train_ddi_modify.py:46-82; with co-attention: train_binary.py:59-141 =
+eval_coattention.py:41-126)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .ggnn import GGNN, PackedAtoms, as_packed
+from .mlp import MLP
+from .packed import PackedMolBatch
+
+
+def sigmoid_cross_entropy(y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """chainer.functions.sigmoid_cross_entropy (train_ddi_modify.py:285): mean over the
+    elements with t != -1 of softplus(y) - t*y."""
+    tf = t.to(y.dtype)
+    mask = t != -1
+    loss = torch.nn.functional.softplus(y) - tf * y
+    loss = torch.where(mask, loss, torch.zeros_like(loss))
+    return loss.sum() / mask.sum().clamp(min=1).to(y.dtype)
+
+
+class GraphConvPredictorForPair(nn.Module):
+    def __init__(self, graph_conv, attn=None, mlp=None, symmetric=None):
+        super().__init__()
+        self.graph_conv = graph_conv
+        self.attn = attn
+        self.mlp = mlp
+        self.symmetric = symmetric
+
+    def _encode(self, atoms_1, adjs_1, atoms_2, adjs_2):
+        """Siamese encoder (train_binary.py:91-94).  A two-sided PackedMolBatch in the first slot
+        encodes both sides in ONE pass (same weights, so it is the same computation)."""
+        if isinstance(atoms_1, PackedMolBatch) and len(atoms_1.side_mols) == 3 and atoms_2 is None:
+            pb = atoms_1
+            g = self.graph_conv(pb)
+            at = self.graph_conv.get_atom_array()
+            B = pb.side_mols[1]
+            return g[:B], g[B:], at, at, (0, B)
+        g1 = self.graph_conv(atoms_1, adjs_1)
+        at1 = self.graph_conv.get_atom_array()
+        g2 = self.graph_conv(atoms_2, adjs_2)
+        at2 = self.graph_conv.get_atom_array()
+        return g1, g2, at1, at2, (0, 0)
+
+    def forward(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
+        g1, g2, at1, at2, mol0 = self._encode(atoms_1, adjs_1, atoms_2, adjs_2)
+        if self.attn is not None:
+            g1, g2 = self.attn(at1, g1, at2, g2, mol0=mol0)                  # train_binary.py:96
+        self.g1, self.g2 = g1, g2
+        if isinstance(self.mlp, MLP):
+            return self.mlp(torch.cat((g1, g2), dim=-1))                     # :98-101
+        return self.mlp(g1, g2)                                              # NTN / HolE / ... :102-116
+
+    def predict(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
+        """train_binary.py:120-127 (sigmoid under no-backprop)."""
+        with torch.no_grad():
+            if self.symmetric is None:
+                return torch.sigmoid(self.forward(atoms_1, adjs_1, atoms_2, adjs_2))
+            if isinstance(atoms_1, PackedMolBatch):
+                raise NotImplementedError("symmetric predict needs the dense four-array form")
+            t1 = torch.sigmoid(self.forward(atoms_1, adjs_1, atoms_2, adjs_2))
+            t2 = torch.sigmoid(self.forward(atoms_2, adjs_2, atoms_1, adjs_1))
+            return torch.maximum(t1, t2) if self.symmetric == 'or' else torch.minimum(t1, t2)
+
+    @staticmethod
+    def loss(y, t):
+        return sigmoid_cross_entropy(y, t)
+
+
+def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=True, attn: Optional[str] = "nie",
+                         head=8, class_num=1, encoder="ggnn", mlp_hidden=(32, 16)):
+    """set_up_predictor counterpart (train_binary.py:144-277) for the configs of BASELINE.json."""
+    if encoder == "ggnn":
+        enc = GGNN(out_dim=out_dim, hidden_dim=hidden_dim, n_layers=n_layers, weight_tying=weight_tying)
+    elif encoder == "relgcn":
+        from .relgcn import RelGCN
+        enc = RelGCN(out_channels=out_dim, ch_list=[hidden_dim] * (n_layers + 1), scale_adj=True)
+    else:
+        raise ValueError('[ERROR] Invalid graph embedding encoder.')
+    a = None
+    if attn in ("nie", "vqa"):
+        from .coattention import NieFineCoattention
+        a = NieFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
+    elif attn is not None:
+        raise ValueError('[ERROR] Invalid Co-Attention Method.')
+    return GraphConvPredictorForPair(enc, a, MLP(class_num, mlp_hidden, in_dim=2 * out_dim))

@@ -1,0 +1,76 @@
+// Internal launch helpers shared by the op-level C-ABI launchers (bmp_ops.hip, bmp_coattn.hip).
+#pragma once
+#include "bmp_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Row GEMM:  Y[N x Nout] = epi( sum_s X_s[N x K_s] (* X2_s) . Wt_s[K_s x Nout] )
+//   * N is a multiple of BMP_R (packed layout), K_s a multiple of 8, ldx/ldx2 multiples of 4,
+//     every X pointer 16-byte aligned.
+//   * Wt_s is K-major ("transposed Linear weight"): element (k, n) at Wt[k*ldw + n].
+//   * one workgroup = one 128-row tile x NT output columns; the row tile is staged through LDS
+//     in 64-wide K chunks, weights stream from L2 straight into MFMA B registers.
+// ---------------------------------------------------------------------------------------------
+struct RGSrc {
+    const float* X;      // [N x K]
+    const float* X2;     // optional elementwise multiplicand of X (same shape), or nullptr
+    const float* Wt;     // [K x >=Nout]
+    int ldx, ldx2, ldw, K;
+};
+
+enum {
+    BMP_EPI_GENERIC = 0,   // v (+bias) (+wdeg.bE) (+add) -> act -> Y / o1 (column split)
+    BMP_EPI_GRU_OUT = 1,   // c = tanh(v + bias); h' = z*c + (1-z)*h  (first: h' = z*c)
+    BMP_EPI_GRU_DRH = 2,   // v = dRH: da_r = v*h*r*(1-r) -> Y ; o1 += v*r
+};
+
+struct RGArgs {
+    RGSrc s[3];
+    int nsrc;
+    int Nout;
+    float* Y; int ldy;
+    const float* bias;               // [Nout] or nullptr
+    // GENERIC extras
+    const float* add; int ldadd;     // added where col < split (or everywhere if split <= 0)
+    const float* wdeg;               // [N x 4] per-row per-bond-type weighted degree, or nullptr
+    const float* bE; int ldbE;       // [4 x Nout] per-bond-type bias
+    int split;                       // column split (<=0: none)
+    int act_lo, act_hi;              // activation below / at-or-above split (act_lo everywhere if no split)
+    float* o1; int ldo1;             // columns >= split go to o1[row, col - split] when o1 != nullptr
+    int accumulate;                  // Y += instead of Y =
+    // GRU extras
+    const float* z; int ldz;
+    const float* h; int ldh;
+    const float* r; int ldr;
+    float* c_out; int ldc;
+    int first;
+};
+
+int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM:  out[K x Nn] (=|+=) sum_rows X[row, k] (* X2) . dY[row, n]
+//   split over row chunks into slabs (deterministic), then reduced.
+// ---------------------------------------------------------------------------------------------
+struct WGArgs {
+    const float* X; const float* X2; int ldx, ldx2;
+    const float* dY; int ldy;
+    int K, Nn, N;
+    float* out; int ldo;             // [K x Nn]
+    int accumulate;
+};
+size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
+int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
+
+// column sums: out[n] (=|+=) sum_rows dY[row, n]
+size_t bmp_colsum_ws_floats(int N, int Nn);
+int bmp_launch_colsum(const float* dY, int ldy, int N, int Nn, float* out, int accumulate, float* ws, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Graph kernels (bmp_graph.hip)
+// ---------------------------------------------------------------------------------------------
+// forward gather: agg[i, e*d + k] = sum_{(j,e) in csr(i)} val * x[j, k]; wdeg[i, e] = sum val
+int bmp_launch_gather_fwd(const float* x, int ldx, int N, int d, const int* ptr, const int* col, const float* val,
+                          float* agg, float* wdeg, hipStream_t st);
+// backward gather (transposed CSR): dx[j, k] (=|+=) sum_{(i,e) in csrT(j)} val * dagg[i, e*d + k]
+int bmp_launch_gather_bwd(const float* dagg, int N, int d, const int* ptrT, const int* colT, const float* valT,
+                          float* dx, int lddx, int accumulate, hipStream_t st);

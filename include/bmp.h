@@ -1,0 +1,90 @@
+/* libbmp_hip -- C ABI of the MI355X-native GCN-BMP hot path (gfx950 only).
+ *
+ * The reference (Minys233/GCN-BMP) has no FFI: its operator boundary is the Python call
+ * protocol of chainer.Chain subclasses.  These entry points are what a
+ * binding for that path would call -- one per reference operator -- and are what
+ * gcn-bmp_amd/bmp/_lib.py binds with ctypes.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch caching allocator), 16-byte aligned;
+ *     float = IEEE fp32, int = int32.  The library never allocates, frees, retains a pointer
+ *     past the call, synchronises the host or keeps global state: a call only enqueues kernels
+ *     on `stream`.
+ *   - row-indexed arrays use the packed layout of bmp/packed.py: N = n_tiles * bmp_tile_rows()
+ *     rows (128 per tile, molecules never straddle a tile, dead rows are zero-weight).
+ *   - weights come in two layouts: "T" = K-major [in x out] (used as the GEMM B operand) and
+ *     "nat" = the reference Linear layout [out x in] (used by the backward-data GEMM).
+ *   - return value 0 = ok; > 0 = hipError_t of a failed launch; < -1000 = argument check failed
+ *     at source line -(ret + 1000).
+ *   - `ws` is caller-provided scratch of at least *_ws_floats() floats.
+ */
+#ifndef BMP_H_
+#define BMP_H_
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* bmp_stream_t; /* == hipStream_t */
+
+enum { BMP_ACT_NONE = 0, BMP_ACT_SIGMOID = 1, BMP_ACT_TANH = 2, BMP_ACT_RELU = 3 };
+
+int bmp_version(void);
+int bmp_tile_rows(void);
+
+/* EmbedAtomID lookup -- chainer_chemistry EmbedAtomID used at models/ggnn.py:85,603
+ * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:].  bwd accumulates INTO dW [V x d]. */
+int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float* out, bmp_stream_t stream);
+int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, bmp_stream_t stream);
+
+/* Message function -- GGNN.update message part models/ggnn.py:215-243 (= GGNNUpdate
+ * models/update/ggnn_update.py:31-50); with WsT/bs/act=TANH the whole RelGCN layer
+ * models/update/relgcn_update.py:24-44 + models/relgcn.py:71.
+ *   out = act( gather_sum(x) . WT + wdeg . bE [+ x . WsT + bs] )
+ * WT [4*d_in x d_out] row e*d_in+k, col c == reference W[4c+e][k]; bE [4 x d_out] == b[4c+e].
+ * Saves agg [N x 4*d_in] and wdeg [N x 4] for the backward. */
+int bmp_msg_fwd(const float* x, int ldx, int n_tiles, int d_in, int d_out, const int* csr_ptr, const int* csr_col,
+                const float* csr_val, const float* WT, const float* bE, const float* WsT, const float* bs, int act,
+                float* agg, float* wdeg, float* out, int ldo, bmp_stream_t stream);
+size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out);
+int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ldo, int act, const float* x, int ldx, int n_tiles,
+                int d_in, int d_out, const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat,
+                const float* Ws, const float* agg, const float* wdeg, float* dx, float* dWT, float* dbE, float* dWsT,
+                float* dbs, float* ws, size_t ws_floats, bmp_stream_t stream);
+
+/* GRU node update -- chainer links.GRU (StatefulGRU) at models/ggnn.py:132,254-262
+ * (models/update/ggnn_update.py:28,61).  first != 0 selects the first-call-after-reset branch.
+ * AT [2d x 3d] rows [h;m] cols [r|z|c] (state terms folded by the caller), UcT [d x d], b [3d].
+ * Saves rz [N x 2d], c [N x d]. */
+int bmp_gru_fwd(const float* h, const float* m, int n_tiles, int d, int first, const float* AT, const float* UcT,
+                const float* b, float* rz, float* c, float* hout, bmp_stream_t stream);
+size_t bmp_gru_bwd_ws_floats(int n_tiles, int d);
+int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float* rz, const float* c, int n_tiles, int d,
+                int first, const float* A, const float* Uc, float* dh, float* dm, float* dAT, float* dUcT, float* db,
+                float* ws, size_t ws_floats, bmp_stream_t stream);
+
+/* Gated-sum readout -- GGNN.readout models/ggnn.py:333-341 and GGNNReadout.__call__
+ * models/readout/ggnn_readout.py:42-57.  g[mol] = sum_rows w * sigmoid(i(.)) * act_j(j(.)).
+ * WT [(d+d0) x 2o] cols [i|j]; h0 may be NULL (d0 ignored).  Saves ij [N x 2o]. */
+int bmp_readout_fwd(const float* h, const float* h0, int n_tiles, int d, int d0, int o, const float* WT, const float* b,
+                    int act_j, const float* row_w, const int* mol_row0, const int* mol_nrows, int n_mols, float* ij,
+                    float* g, bmp_stream_t stream);
+size_t bmp_readout_bwd_ws_floats(int n_tiles, int d, int d0, int o);
+int bmp_readout_bwd(const float* dg, const float* h, const float* h0, int n_tiles, int d, int d0, int o,
+                    const float* Wnat, const float* ij, int act_j, const float* row_w, const int* mol_row0,
+                    const int* mol_nrows, int n_mols, float* dh, float* dh0, float* dWT, float* db, float* ws,
+                    size_t ws_floats, bmp_stream_t stream);
+
+/* GraphLinear on row tiles -- chainer_chemistry GraphLinear (models/ggnn.py:16,88,135,139;
+ * nie_coattention.py:325-329): Y = act(X . WT + b); weight/bias gradients over N rows. */
+int bmp_linear_fwd(const float* X, int ldx, int n_tiles, int K, int Nout, const float* WT, int ldw, const float* b,
+                   int act, float* Y, int ldy, bmp_stream_t stream);
+size_t bmp_wgrad_ws_floats_c(int N, int K, int Nn);
+int bmp_linear_wgrad(const float* X, int ldx, const float* dY, int ldy, int N, int K, int Nn, float* dWT, float* db,
+                     float* ws, size_t ws_floats, bmp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMP_H_ */
