@@ -1,0 +1,176 @@
+"""Drug-pair co-attention modules with the reference's signatures
+(models/coattention/*.py: ``X(hidden_dim, out_dim, head, activation=...)``,
+``__call__(atoms_1, g_1, atoms_2, g_2) -> (compact_1, compact_2)``).
+
+``atoms_k`` is what ``graph_conv.get_atom_array()`` returned: a PackedAtoms (per-row atom
+states of a packed batch).  The fine family ignores g_1/g_2 (nie_coattention.py:335-370).
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import numpy as np
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, ptr, stream
+from .functional import ACT, _ws
+from .ggnn import Linear, PackedAtoms
+
+
+class Bilinear(nn.Module):
+    """Parameters of chainer.links.Bilinear(l, r, o): W [l x r x o], V1 [l x o], V2 [r x o], b [o]."""
+
+    def __init__(self, left: int, right: int, out: int):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(left, right, out) / math.sqrt(left))
+        self.V1 = nn.Parameter(torch.randn(left, out) / math.sqrt(left))
+        self.V2 = nn.Parameter(torch.randn(right, out) / math.sqrt(right))
+        self.b = nn.Parameter(torch.zeros(out))
+
+
+def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
+    """Row tensors and per-pair row ranges of the two sides.
+
+    * one two-sided batch (fast path): side 1 = tiles [0, T1), side 2 = tiles [T1, T); the row
+      tensors are views of the same buffer and side-2 row offsets are made relative to its view;
+    * two single-sided batches (the reference's call order: graph_conv twice, then attn)."""
+    pb1, pb2 = at1.pb, at2.pb
+    R = pb1.R
+    if pb1 is pb2 and len(pb1.side_mols) == 3:
+        key = "pair_meta"
+        if key not in pb1._cache:
+            B = pb1.side_mols[1]
+            if pb1.side_mols[2] != 2 * B:
+                raise ValueError("co-attention needs as many side-2 as side-1 molecules")
+            T1 = pb1.side_tiles[1]
+            nr = pb1.mol_nrows_host
+            coff = np.concatenate(([0], np.cumsum(nr[:B] * nr[B:])))
+            pb1._cache[key] = dict(
+                B=B, T1=T1, T2=pb1.side_tiles[2] - T1,
+                r1=pb1.mol_row0[:B].contiguous(), n1=pb1.mol_nrows[:B].contiguous(),
+                r2=(pb1.mol_row0[B:] - T1 * R).contiguous(), n2=pb1.mol_nrows[B:].contiguous(),
+                coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]),
+                maxn=int(nr.max()))
+        m = pb1._cache[key]
+        N1 = m["T1"] * R
+        X1, X2 = at1.rows[:N1], at1.rows[N1:]
+        w1, w2 = pb1.row_w[:N1], pb1.row_w[N1:]
+        return X1, X2, w1, w2, m, True
+    if at1.rows is at2.rows:
+        raise ValueError("both sides point at the same rows of a one-sided batch")
+    if pb1.n_mols != pb2.n_mols:
+        raise ValueError("co-attention needs as many side-2 as side-1 molecules")
+    nr1, nr2 = pb1.mol_nrows_host, pb2.mol_nrows_host
+    coff = np.concatenate(([0], np.cumsum(nr1 * nr2)))
+    m = dict(B=pb1.n_mols, T1=pb1.n_tiles, T2=pb2.n_tiles, r1=pb1.mol_row0, n1=pb1.mol_nrows, r2=pb2.mol_row0,
+             n2=pb2.mol_nrows, coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]),
+             maxn=int(max(nr1.max(), nr2.max())))
+    return at1.rows, at2.rows, pb1.row_w, pb2.row_w, m, False
+
+
+class NieCoattnFn(Function):
+    """bmp_coattn_nie_fwd / _bwd.  Inputs in kernel layout (see include/bmp.h)."""
+
+    @staticmethod
+    def forward(ctx, X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cbias, w1, w2, meta, d, o, H, act):
+        L = _lib.lib()
+        dev = X1.device
+        B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
+        ZC = L.bmp_coattn_zcols(o, H)
+        X1 = X1.contiguous(); X2 = X2.contiguous()
+        WbT, ZW1T, ZW2T, zb = WbT.contiguous(), ZW1T.contiguous(), ZW2T.contiguous(), zb.contiguous()
+        wa1, wa2, cbias = wa1.contiguous(), wa2.contiguous(), cbias.contiguous()
+        N1, N2 = X1.shape[0], X2.shape[0]
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        Q2, Z1, Z2 = f(N2, d), f(N1, ZC), f(N2, ZC)
+        Cbuf = f(max(meta["ctotal"], 1))
+        H1, H2 = torch.zeros(N1, H, device=dev), torch.zeros(N2, H, device=dev)
+        al1, al2 = torch.zeros(N1, device=dev), torch.zeros(N2, device=dev)
+        out1, out2 = f(B, o), f(B, o)
+        check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
+                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, meta["maxn"],
+                                   ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
+                                   ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(out1),
+                                   ptr(out2), stream()), "bmp_coattn_nie_fwd")
+        ctx.save_for_backward(X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
+        ctx.meta, ctx.dims = meta, (d, o, H, act, ZC)
+        return out1, out2
+
+    @staticmethod
+    def backward(ctx, dout1, dout2):
+        L = _lib.lib()
+        X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2 = ctx.saved_tensors
+        meta = ctx.meta
+        d, o, H, act, ZC = ctx.dims
+        dev = X1.device
+        B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
+        dout1, dout2 = dout1.contiguous(), dout2.contiguous()
+        Wb = WbT.t().contiguous()
+        ZW1, ZW2 = ZW1T.t().contiguous(), ZW2T.t().contiguous()
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        dX1, dX2 = f(*X1.shape), f(*X2.shape)
+        dWbT, dZW1T, dZW2T, dzb, dwa = f(d, d), f(d, ZC), f(d, ZC), f(ZC), f(2 * H + 1)
+        nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
+        ws = _ws(nws, dev)
+        check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1),
+                                   ptr(meta["r1"]), ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]),
+                                   ptr(meta["coff"]), B, meta["maxn"], ptr(Wb), ptr(ZW1), ptr(ZW2), ptr(wa1), ptr(wa2),
+                                   ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
+                                   ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
+                                   stream()), "bmp_coattn_nie_bwd")
+        return (dX1, dX2, dWbT, dZW1T, dZW2T, dzb, dwa[:H], dwa[H:2 * H], dwa[2 * H:], None, None, None, None, None,
+                None, None)
+
+
+class NieFineCoattention(nn.Module):
+    """models/coattention/nie_coattention.py:312-396."""
+
+    def __init__(self, hidden_dim, out_dim, head, activation="identity"):
+        super().__init__()
+        if head >= 16:
+            raise ValueError("head must be < 16")
+        if hidden_dim % 8 or out_dim % 4:
+            raise ValueError("hidden_dim must be a multiple of 8 and out_dim of 4")
+        self.energy_layer = Bilinear(hidden_dim, hidden_dim, 1)
+        self.attention_layer_1 = Linear(head, 1, nobias=True)
+        self.attention_layer_2 = Linear(head, 1, nobias=True)
+        self.lt_layer_1 = Linear(hidden_dim, head, nobias=True)
+        self.lt_layer_2 = Linear(hidden_dim, head, nobias=True)
+        self.j_layer = Linear(hidden_dim, out_dim)
+        self.hidden_dim, self.out_dim, self.head = hidden_dim, out_dim, head
+        if callable(activation):
+            activation = getattr(activation, "__name__", str(activation))
+        if activation not in ("identity", "tanh", "sigmoid", "relu"):
+            raise ValueError(f"unsupported activation {activation!r}")
+        self.activation = activation
+
+    def _kernel_weights(self):
+        d, o, H = self.hidden_dim, self.out_dim, self.head
+        ZC = _lib.lib().bmp_coattn_zcols(o, H)
+        E = self.energy_layer
+        dev = E.W.device
+        WbT = E.W[:, :, 0].t()                                                  # [q][p] = W[p][q]
+        pad = torch.zeros(d, ZC - o - H - 1, device=dev)
+        ZW1T = torch.cat((self.j_layer.W.t(), self.lt_layer_1.W.t(), E.V1, pad), dim=1)
+        ZW2T = torch.cat((self.j_layer.W.t(), self.lt_layer_2.W.t(), E.V2, pad), dim=1)
+        zb = torch.cat((self.j_layer.b, torch.zeros(ZC - o, device=dev)))
+        return WbT, ZW1T, ZW2T, zb, self.attention_layer_1.W[0], self.attention_layer_2.W[0], E.b
+
+    def forward(self, atoms_1, g_1, atoms_2, g_2, **_) -> Tuple[torch.Tensor, torch.Tensor]:
+        if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
+            raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
+        WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = self._kernel_weights()
+        return NieCoattnFn.apply(X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cb, w1, w2, meta, self.hidden_dim,
+                                 self.out_dim, self.head, ACT[self.activation])
+
+
+class VQAParallelCoattention(NieFineCoattention):
+    """models/coattention/vqa_parallel_coattention.py:13-102: the Nie computation with tanh default."""
+
+    def __init__(self, hidden_dim, out_dim, head, activation="tanh"):
+        super().__init__(hidden_dim, out_dim, head, activation)

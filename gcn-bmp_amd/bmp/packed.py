@@ -125,6 +125,7 @@ class PackedMolBatch:
     n_real_atoms: int = 0
     n_edges: int = 0
     max_rows_per_mol: int = 0
+    mol_nrows_host: Optional[np.ndarray] = None   # host copy of mol_nrows (pair metadata without a device sync)
     _cache: dict = field(default_factory=dict, repr=False)
 
     @property
@@ -210,6 +211,7 @@ def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
         dense_maps=dmaps,
         n_real_atoms=int((flat_w == 1).sum()), n_edges=int(len(e_dst)),
         max_rows_per_mol=int(inst_nrows.max()) if I else 0,
+        mol_nrows_host=inst_nrows.astype(np.int64),
     )
 
 

@@ -1,0 +1,586 @@
+// Fine-grained drug-pair co-attention (NieFineCoattention / VQAParallelCoattention,
+// models/coattention/nie_coattention.py:335-396, vqa_parallel_coattention.py:42-102) on packed rows.
+//
+// The reference tiles both atom sets to (mb*N2*N1, d) and lets chainer Bilinear materialise
+// (mb*N2*N1, d*d) outer products.  Here:
+//   stage A (row GEMMs):  Q2 = X2 . W^T (the bilinear form applied once per atom),
+//                         Z_k = X_k . [Wj^T | Wl_k^T | V_k]  -> J (o cols, +bj) | P (H cols) | v (1 col)
+//   stage B (one workgroup per pair): S = Q2 . X1^T as 32x32 MFMA tiles, C = act(S + v1 + v2 + c),
+//                         both softmaxes of C, the head projections, the atom softmax and the
+//                         pooled outputs -- C never leaves LDS except once for the backward.
+// Every sum over atoms carries the row multiplicities w (virtual pad rows, bmp/packed.py), which
+// reproduces the reference's unmasked zero-padding exactly.
+#include <string.h>
+#include "bmp_kernels.h"
+
+#define CO_MAXN 128          // rows per molecule never exceed the tile size
+#define CO_MAXH 16
+
+struct CoArgs {
+    const float* X1; const float* X2;          // [N1 x d], [N2 x d]
+    const float* Q2;                           // [N2 x d]
+    const float* Z1; const float* Z2; int ZC;  // [N x ZC]: J (o) | P (H) | v (1) | pad
+    const float* w1; const float* w2;
+    const int* r1; const int* n1; const int* r2; const int* n2;   // per pair row range
+    const long long* coff;                     // per pair offset into Cbuf
+    const float* wa1; const float* wa2; const float* cbias;
+    int d, o, H, act, ldc;
+    float* Cbuf;                               // ragged: pair b holds C (n2 x n1), row-major
+    float* H1; float* H2;                      // [N x H] tanh outputs
+    float* al1; float* al2;                    // [N] attention weights
+    float* out1; float* out2;                  // [B x o]
+    // backward
+    const float* dout1; const float* dout2;
+    float* dQ2; float* dX1;                    // [N2 x d], [N1 x d]
+    float* dZ1; float* dZ2;                    // [N x ZC]
+    float* dpart;                              // [B x (2H + 1)]: dwa1 | dwa2 | dc
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// LDS carve-up shared by forward and backward
+struct CoLds {
+    float* Cs;      // [n2p x ldc]
+    float* dSs;     // [n2p x ldc]   (backward only)
+    float* P1s;     // [MAXN x H]
+    float* P2s;
+    float* dH1s;    // [MAXN x H]    (backward only)
+    float* dH2s;
+    float* w1s; float* w2s; float* v2s;
+    float* cst;     // cmax[MAXN] | invD2[MAXN] | rmax[MAXN] | invD1[MAXN]
+    float* s1; float* s2;            // scores / alphas
+    float* dots;    // [2*MAXN]
+};
+
+__device__ __forceinline__ CoLds co_carve(float* base, int n2p, int ldc, int H, bool bwd) {
+    CoLds L;
+    float* p = base;
+    L.Cs = p; p += (size_t)n2p * ldc;
+    L.dSs = p; if (bwd) p += (size_t)n2p * ldc;
+    L.P1s = p; p += CO_MAXN * H;
+    L.P2s = p; p += CO_MAXN * H;
+    L.dH1s = p; if (bwd) p += CO_MAXN * H;
+    L.dH2s = p; if (bwd) p += CO_MAXN * H;
+    L.w1s = p; p += CO_MAXN;
+    L.w2s = p; p += CO_MAXN;
+    L.v2s = p; p += CO_MAXN;
+    L.cst = p; p += 4 * CO_MAXN;
+    L.s1 = p; p += CO_MAXN;
+    L.s2 = p; p += CO_MAXN;
+    L.dots = p; p += 2 * CO_MAXN;
+    return L;
+}
+
+static size_t co_lds_floats(int n2p, int ldc, int H, bool bwd) {
+    size_t f = (size_t)n2p * ldc * (bwd ? 2 : 1) + (size_t)CO_MAXN * H * (bwd ? 4 : 2) + 3 * CO_MAXN + 4 * CO_MAXN +
+               2 * CO_MAXN + 2 * CO_MAXN;
+    return f;
+}
+
+// column / row softmax statistics of C with multiplicities:
+//   cmax[j], invD2[j] = 1 / sum_i w2_i exp(C[i,j]-cmax[j])   (softmax over i, nie_coattention.py:347)
+//   rmax[i], invD1[i] = 1 / sum_j w1_j exp(C[i,j]-rmax[i])   (softmax over j, :349)
+__device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc) {
+    const int tid = threadIdx.x;
+    if (tid < CO_MAXN) {
+        const int j = tid;
+        if (j < n1) {
+            float mx = -INFINITY;
+            for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
+            float s = 0.f;
+            for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) s += L.w2s[i] * expf(L.Cs[i * ldc + j] - mx);
+            L.cst[j] = mx; L.cst[CO_MAXN + j] = 1.f / s;
+        }
+    } else {
+        const int i = tid - CO_MAXN;
+        if (i < n2) {
+            float mx = -INFINITY;
+            for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
+            float s = 0.f;
+            for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) s += L.w1s[j] * expf(L.Cs[i * ldc + j] - mx);
+            L.cst[2 * CO_MAXN + i] = mx; L.cst[3 * CO_MAXN + i] = 1.f / s;
+        }
+    }
+}
+
+// L2[i,j] (softmax over i) and L1[j,i] (softmax over j); zero-weight rows get weight 0 in every sum,
+// so their (possibly huge) exponent is never used.
+__device__ __forceinline__ float co_L2(const CoLds& L, int i, int j, int ldc) {
+    return L.w2s[i] > 0.f ? expf(L.Cs[i * ldc + j] - L.cst[j]) * L.cst[CO_MAXN + j] : 0.f;
+}
+__device__ __forceinline__ float co_L1(const CoLds& L, int i, int j, int ldc) {
+    return L.w1s[j] > 0.f ? expf(L.Cs[i * ldc + j] - L.cst[2 * CO_MAXN + i]) * L.cst[3 * CO_MAXN + i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
+    const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
+    const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
+    const CoLds L = co_carve(lds_raw, nb2 * 32, ldc, H, false);
+    const float cb = a.cbias[0];
+
+    for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n2 * H; idx += 256) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
+    if (tid < n1) L.w1s[tid] = a.w1[r1 + tid];
+    if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
+        const int i = tid - CO_MAXN;
+        L.w2s[i] = a.w2[r2 + i];
+        L.v2s[i] = a.Z2[(size_t)(r2 + i) * ZC + o + H];
+    }
+    __syncthreads();
+
+    // ---- energy tiles: S = Q2 . X1^T on the matrix cores, one 32x32 block per wave at a time ----
+    for (int blk = wave; blk < nb2 * nb1; blk += 4) {
+        const int bi = blk / nb1, bj = blk % nb1;
+        int ia = bi * 32 + l31; ia = ia < n2 ? ia : n2 - 1;
+        int ja = bj * 32 + l31; ja = ja < n1 ? ja : n1 - 1;
+        const float* qa = a.Q2 + (size_t)(r2 + ia) * d + 4 * hi;
+        const float* xb = a.X1 + (size_t)(r1 + ja) * d + 4 * hi;
+        f32x16 acc;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        for (int k0 = 0; k0 < d; k0 += 8) {
+            const f32x4 av = *(const f32x4*)(qa + k0);
+            const f32x4 bv = *(const f32x4*)(xb + k0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = bmp_mfma(av[t], bv[t], acc);
+        }
+        const int j = bj * 32 + l31;
+        const float v1j = j < n1 ? a.Z1[(size_t)(r1 + j) * ZC + o + H] : 0.f;
+        float* cg = a.Cbuf + a.coff[b];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = bi * 32 + bmp_acc_row(reg, lane);
+            if (i < n2 && j < n1) {
+                const float cv = bmp_act(a.act, acc[reg] + v1j + L.v2s[i] + cb);
+                L.Cs[i * ldc + j] = cv;
+                cg[(size_t)i * n1 + j] = cv;
+            }
+        }
+    }
+    __syncthreads();
+    co_stats(L, n1, n2, ldc);
+    __syncthreads();
+
+    // ---- head projections: H1 = tanh(P1 + L1 . P2), H2 = tanh(P2 + L2 . P1)  (:352-362) ----
+    if (tid < CO_MAXN) {
+        const int j = tid;
+        if (j < n1) {
+            float acc[CO_MAXH];
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) acc[h] = 0.f;
+            for (int i = 0; i < n2; ++i) {
+                const float e = L.w2s[i] * co_L1(L, i, j, ldc);
+#pragma unroll
+                for (int h = 0; h < CO_MAXH; ++h) if (h < H) acc[h] += e * L.P2s[i * H + h];
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+                const float hv = bmp_tanh(L.P1s[j * H + h] + acc[h]);
+                a.H1[(size_t)(r1 + j) * H + h] = hv;
+                s += hv * a.wa1[h];
+            }
+            L.s1[j] = s;
+        }
+    } else {
+        const int i = tid - CO_MAXN;
+        if (i < n2) {
+            float acc[CO_MAXH];
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) acc[h] = 0.f;
+            for (int j = 0; j < n1; ++j) {
+                const float e = L.w1s[j] * co_L2(L, i, j, ldc);
+#pragma unroll
+                for (int h = 0; h < CO_MAXH; ++h) if (h < H) acc[h] += e * L.P1s[j * H + h];
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+                const float hv = bmp_tanh(L.P2s[i * H + h] + acc[h]);
+                a.H2[(size_t)(r2 + i) * H + h] = hv;
+                s += hv * a.wa2[h];
+            }
+            L.s2[i] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- atom softmax (default axis=1 = atoms, :364-366), wave 0: side 1, wave 1: side 2 ----
+    if (wave < 2) {
+        float* sc = wave == 0 ? L.s1 : L.s2;
+        const float* ww = wave == 0 ? L.w1s : L.w2s;
+        const int n = wave == 0 ? n1 : n2;
+        float mx = -INFINITY;
+        for (int k = lane; k < n; k += 64) if (ww[k] > 0.f) mx = fmaxf(mx, sc[k]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int k = lane; k < n; k += 64) if (ww[k] > 0.f) s += ww[k] * expf(sc[k] - mx);
+        s = wave_sum(s);
+        float* alg = wave == 0 ? a.al1 + r1 : a.al2 + r2;
+        for (int k = lane; k < n; k += 64) {
+            const float al = ww[k] > 0.f ? expf(sc[k] - mx) / s : 0.f;
+            sc[k] = al;
+            alg[k] = al;
+        }
+    }
+    __syncthreads();
+
+    // ---- pooled outputs: compact_k = sum_atoms w * alpha * j_layer(atoms)  (:368-369) ----
+    {
+        const int side = tid >> 7, t = tid & 127;
+        const float* Z = side == 0 ? a.Z1 + (size_t)r1 * ZC : a.Z2 + (size_t)r2 * ZC;
+        const float* al = side == 0 ? L.s1 : L.s2;
+        const float* ww = side == 0 ? L.w1s : L.w2s;
+        const int n = side == 0 ? n1 : n2;
+        float* out = (side == 0 ? a.out1 : a.out2) + (size_t)b * o;
+        for (int c = t; c < o; c += 128) {
+            float acc = 0.f;
+            for (int k = 0; k < n; ++k) acc += ww[k] * al[k] * Z[(size_t)k * ZC + c];
+            out[c] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
+    const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
+    const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
+    const int n1p = nb1 * 32, n2p = nb2 * 32;
+    const CoLds L = co_carve(lds_raw, ldc - 1, ldc, H, true);
+
+    // ---- load the pair's saved state ----
+    for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n2 * H; idx += 256) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
+    if (tid < n1) { L.w1s[tid] = a.w1[r1 + tid]; L.s1[tid] = a.al1[r1 + tid]; }
+    if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
+        const int i = tid - CO_MAXN;
+        L.w2s[i] = a.w2[r2 + i]; L.s2[i] = a.al2[r2 + i];
+    }
+    {
+        const float* cg = a.Cbuf + a.coff[b];
+        for (int idx = tid; idx < n2p * ldc; idx += 256) { L.dSs[idx] = 0.f; }
+        for (int idx = tid; idx < n2 * n1; idx += 256) L.Cs[(idx / n1) * ldc + idx % n1] = cg[idx];
+    }
+    __syncthreads();
+
+    // ---- pooled-output backward: dJ = w*alpha*dout ; dot[k] = J[k,:] . dout ----
+    for (int row = wave; row < n1 + n2; row += 4) {
+        const int side = row < n1 ? 0 : 1;
+        const int k = side == 0 ? row : row - n1;
+        const size_t gr = side == 0 ? (size_t)(r1 + k) : (size_t)(r2 + k);
+        const float* Z = (side == 0 ? a.Z1 : a.Z2) + gr * ZC;
+        float* dZ = (side == 0 ? a.dZ1 : a.dZ2) + gr * ZC;
+        const float* dout = (side == 0 ? a.dout1 : a.dout2) + (size_t)b * o;
+        const float wa = (side == 0 ? L.w1s[k] * L.s1[k] : L.w2s[k] * L.s2[k]);
+        float dot = 0.f;
+        for (int c = lane; c < o; c += 64) {
+            const float g = dout[c];
+            dot += Z[c] * g;
+            dZ[c] = wa * g;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) L.dots[side * CO_MAXN + k] = dot;
+    }
+    __syncthreads();
+
+    // ---- atom softmax backward: ds_k = alpha_k (dalpha_k - w_k T), dalpha_k = w_k dot_k, T = sum alpha dalpha ----
+    if (wave < 2) {
+        const float* al = wave == 0 ? L.s1 : L.s2;
+        const float* ww = wave == 0 ? L.w1s : L.w2s;
+        float* dt = L.dots + wave * CO_MAXN;
+        const int n = wave == 0 ? n1 : n2;
+        float tsum = 0.f;
+        for (int k = lane; k < n; k += 64) tsum += al[k] * ww[k] * dt[k];
+        tsum = wave_sum(tsum);
+        for (int k = lane; k < n; k += 64) dt[k] = al[k] * (ww[k] * dt[k] - ww[k] * tsum);     // = ds_k
+    }
+    __syncthreads();
+    // dHpre[k,h] = ds_k * wa[h] * (1 - H^2) ; per-pair partial of dwa[h] = sum_k ds_k H[k,h]
+    for (int idx = tid; idx < (n1 + n2) * H; idx += 256) {
+        const int row = idx / H, h = idx % H;
+        const int side = row < n1 ? 0 : 1;
+        const int k = side == 0 ? row : row - n1;
+        const float hv = side == 0 ? a.H1[(size_t)(r1 + k) * H + h] : a.H2[(size_t)(r2 + k) * H + h];
+        const float ds = L.dots[side * CO_MAXN + k];
+        const float wa = side == 0 ? a.wa1[h] : a.wa2[h];
+        (side == 0 ? L.dH1s : L.dH2s)[k * H + h] = ds * wa * (1.f - hv * hv);
+    }
+    if (tid < 2 * H) {
+        const int side = tid / H, h = tid % H;
+        const int n = side == 0 ? n1 : n2;
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) {
+            const float hv = side == 0 ? a.H1[(size_t)(r1 + k) * H + h] : a.H2[(size_t)(r2 + k) * H + h];
+            acc += L.dots[side * CO_MAXN + k] * hv;
+        }
+        a.dpart[(size_t)b * (2 * H + 1) + side * H + h] = acc;
+    }
+    co_stats(L, n1, n2, ldc);
+    __syncthreads();
+
+    // ---- softmax-of-C backward.  L1 path (threads over i) writes dS, then the L2 path (threads over j)
+    //      adds its part and applies act'(C).  dP1/dP2 fall out of the same loops. ----
+    if (tid >= CO_MAXN) {
+        const int i = tid - CO_MAXN;
+        if (i < n2) {
+            float p2[CO_MAXH], dp2[CO_MAXH];
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) { p2[h] = h < H ? L.P2s[i * H + h] : 0.f; dp2[h] = h < H ? L.dH2s[i * H + h] : 0.f; }
+            const float w2i = L.w2s[i];
+            float U = 0.f;
+            for (int j = 0; j < n1; ++j) {
+                const float l1 = co_L1(L, i, j, ldc);
+                float g = 0.f;
+#pragma unroll
+                for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+                    const float dh = L.dH1s[j * H + h];
+                    g += dh * p2[h];
+                    dp2[h] += w2i * l1 * dh;
+                }
+                U += l1 * (w2i * g);
+            }
+            for (int j = 0; j < n1; ++j) {
+                const float l1 = co_L1(L, i, j, ldc);
+                float g = 0.f;
+#pragma unroll
+                for (int h = 0; h < CO_MAXH; ++h) if (h < H) g += L.dH1s[j * H + h] * p2[h];
+                L.dSs[i * ldc + j] = l1 * (w2i * g) - L.w1s[j] * l1 * U;
+            }
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) if (h < H) a.dZ2[(size_t)(r2 + i) * ZC + o + h] = dp2[h];
+        }
+    }
+    __syncthreads();
+    if (tid < CO_MAXN) {
+        const int j = tid;
+        if (j < n1) {
+            float p1[CO_MAXH], dp1[CO_MAXH];
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) { p1[h] = h < H ? L.P1s[j * H + h] : 0.f; dp1[h] = h < H ? L.dH1s[j * H + h] : 0.f; }
+            const float w1j = L.w1s[j];
+            float U = 0.f;
+            for (int i = 0; i < n2; ++i) {
+                const float l2 = co_L2(L, i, j, ldc);
+                float g = 0.f;
+#pragma unroll
+                for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+                    const float dh = L.dH2s[i * H + h];
+                    g += dh * p1[h];
+                    dp1[h] += w1j * l2 * dh;
+                }
+                U += l2 * (w1j * g);
+            }
+            float dv1 = 0.f;
+            for (int i = 0; i < n2; ++i) {
+                const float l2 = co_L2(L, i, j, ldc);
+                float g = 0.f;
+#pragma unroll
+                for (int h = 0; h < CO_MAXH; ++h) if (h < H) g += L.dH2s[i * H + h] * p1[h];
+                const float dc = L.dSs[i * ldc + j] + l2 * (w1j * g) - L.w2s[i] * l2 * U;
+                const float ds = dc * bmp_dact(a.act, L.Cs[i * ldc + j]);
+                L.dSs[i * ldc + j] = ds;
+                dv1 += ds;
+            }
+#pragma unroll
+            for (int h = 0; h < CO_MAXH; ++h) if (h < H) a.dZ1[(size_t)(r1 + j) * ZC + o + h] = dp1[h];
+            a.dZ1[(size_t)(r1 + j) * ZC + o + H] = dv1;
+        }
+    }
+    __syncthreads();
+    if (tid >= CO_MAXN) {          // dv2[i] = sum_j dS[i,j] ; dc = sum_i dv2[i]
+        const int i = tid - CO_MAXN;
+        float dv2 = 0.f;
+        if (i < n2) {
+            for (int j = 0; j < n1; ++j) dv2 += L.dSs[i * ldc + j];
+            a.dZ2[(size_t)(r2 + i) * ZC + o + H] = dv2;
+        }
+        const float tot = wave_sum(dv2);
+        if (lane == 0) L.dots[wave - 2] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = L.dots[0] + L.dots[1];
+
+    // ---- energy backward on the matrix cores: dQ2 = dS . X1 ; dX1 = dS^T . Q2 ----
+    const int ncb = (d + 31) >> 5;
+    for (int blk = wave; blk < (nb2 + nb1) * ncb; blk += 4) {
+        const bool isq = blk < nb2 * ncb;
+        const int bl = isq ? blk : blk - nb2 * ncb;
+        const int br = bl / ncb, bc = bl % ncb;
+        int col = bc * 32 + l31;
+        const int colc = col < d ? col : d - 1;
+        const int kn = isq ? n1 : n2;                // reduction length (atoms of the other side)
+        const int knp = isq ? n1p : n2p;
+        const float* src = isq ? a.X1 + (size_t)r1 * d : a.Q2 + (size_t)r2 * d;
+        f32x16 acc;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        for (int k0 = 0; k0 < knp; k0 += 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = k0 + 4 * hi + t;
+                const int kc = k < kn ? k : kn - 1;          // padded k: dS is 0 there
+                const float av = isq ? L.dSs[(br * 32 + l31) * ldc + k] : L.dSs[k * ldc + br * 32 + l31];
+                const float bv = src[(size_t)kc * d + colc];
+                acc = bmp_mfma(av, bv, acc);
+            }
+        }
+        float* dst = isq ? a.dQ2 + (size_t)r2 * d : a.dX1 + (size_t)r1 * d;
+        const int nrow = isq ? n2 : n1;
+        if (col < d) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rr = br * 32 + bmp_acc_row(reg, lane);
+                if (rr < nrow) dst[(size_t)rr * d + col] = acc[reg];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static int co_set_lds(const void* fn, size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// ZC = o + H + 1 rounded up to a multiple of 8: J (o) | P (H) | v | pad
+extern "C" int bmp_coattn_zcols(int o, int H) { return (o + H + 1 + 7) & ~7; }
+
+// Forward.  WbT [d x d] = W (bilinear form, [p][q]) so that Q2 = X2 . W^T uses it K-major as [q][p]:
+// pass WbT[q*d + p] = W[p][q].  ZW1T/ZW2T [d x ZC] K-major columns [Wj^T | Wl_k^T | V_k | 0]; zb [ZC] = [bj | 0].
+extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act,
+                                  const float* w1, const int* r1, const int* n1, const float* w2, const int* r2,
+                                  const int* n2, const long long* coff, int B, int maxn, const float* WbT,
+                                  const float* ZW1T, const float* ZW2T, const float* zb, const float* wa1,
+                                  const float* wa2, const float* cbias, float* Q2, float* Z1, float* Z2, float* Cbuf,
+                                  float* H1, float* H2, float* al1, float* al2, float* out1, float* out2, hipStream_t st) {
+    BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
+    BMP_REQUIRE(maxn > 0 && maxn <= CO_MAXN);
+    const int ZC = bmp_coattn_zcols(o, H);
+    int rc;
+    {
+        RGArgs g; memset(&g, 0, sizeof(g));
+        g.s[0] = RGSrc{X2, nullptr, WbT, d, 0, d, d};
+        g.nsrc = 1; g.Nout = d; g.Y = Q2; g.ldy = d;
+        if ((rc = bmp_launch_rowgemm(g, n_tiles2, BMP_EPI_GENERIC, st))) return rc;
+    }
+    for (int s = 0; s < 2; ++s) {
+        RGArgs g; memset(&g, 0, sizeof(g));
+        g.s[0] = RGSrc{s == 0 ? X1 : X2, nullptr, s == 0 ? ZW1T : ZW2T, d, 0, ZC, d};
+        g.nsrc = 1; g.Nout = ZC; g.Y = s == 0 ? Z1 : Z2; g.ldy = ZC; g.bias = zb;
+        if ((rc = bmp_launch_rowgemm(g, s == 0 ? n_tiles1 : n_tiles2, BMP_EPI_GENERIC, st))) return rc;
+    }
+    const int np = (maxn + 31) & ~31;
+    const int ldc = np + 1;
+    const size_t lds = co_lds_floats(np, ldc, H, false) * sizeof(float);
+    BMP_REQUIRE(lds <= 160 * 1024);
+    if ((rc = co_set_lds((const void*)k_coattn_fwd, 160 * 1024))) return rc;
+    CoArgs a; memset(&a, 0, sizeof(a));
+    a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
+    a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.ldc = ldc;
+    a.Cbuf = Cbuf; a.H1 = H1; a.H2 = H2; a.al1 = al1; a.al2 = al2; a.out1 = out1; a.out2 = out2;
+    hipLaunchKernelGGL(k_coattn_fwd, dim3(B), dim3(256), lds, st, a);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B) {
+    const int ZC = bmp_coattn_zcols(o, H);
+    const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
+    const int Nm = N1 > N2 ? N1 : N2;
+    size_t slab = bmp_wgrad_ws_floats(Nm, d, d);
+    size_t s2 = bmp_wgrad_ws_floats(Nm, d, ZC);
+    if (s2 > slab) slab = s2;
+    size_t s3 = bmp_colsum_ws_floats(Nm, ZC);
+    if (s3 > slab) slab = s3;
+    size_t s4 = bmp_colsum_ws_floats(B, 2 * H + 1);
+    if (s4 > slab) slab = s4;
+    // dQ2 [N2 x d] | dZ1 [N1 x ZC] | dZ2 [N2 x ZC] | dpart [B x (2H+1)] | slab
+    return (size_t)N2 * d + (size_t)(N1 + N2) * ZC + (size_t)B * (2 * H + 1) + slab;
+}
+
+// Backward.  Wb [d x d] = W natural ([p][q]) (dX2 += dQ2 . W); ZW1/ZW2 [ZC x d] = transposes of ZW*T.
+// Outputs: dX1, dX2 (written), dWbT [d x d], dZW1T/dZW2T [d x ZC], dzb [ZC] (sum of both sides),
+// dwa [2H + 1] = dwa1 | dwa2 | dc.
+extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
+                                  int n_tiles2, int d, int o, int H, int act, const float* w1, const int* r1,
+                                  const int* n1, const float* w2, const int* r2, const int* n2, const long long* coff,
+                                  int B, int maxn, const float* Wb, const float* ZW1, const float* ZW2, const float* wa1,
+                                  const float* wa2, const float* Q2, const float* Z1, const float* Z2, const float* Cbuf,
+                                  const float* H1, const float* H2, const float* al1, const float* al2, float* dX1,
+                                  float* dX2, float* dWbT, float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws,
+                                  size_t ws_floats, hipStream_t st) {
+    BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
+    BMP_REQUIRE(maxn > 0 && maxn <= CO_MAXN);
+    BMP_REQUIRE(ws_floats >= bmp_coattn_nie_bwd_ws_floats(n_tiles1, n_tiles2, d, o, H, B));
+    const int ZC = bmp_coattn_zcols(o, H);
+    const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
+    float* dQ2 = ws;
+    float* dZ1 = dQ2 + (size_t)N2 * d;
+    float* dZ2 = dZ1 + (size_t)N1 * ZC;
+    float* dpart = dZ2 + (size_t)N2 * ZC;
+    float* slab = dpart + (size_t)B * (2 * H + 1);
+    hipError_t e;
+    // rows outside every pair (dead rows) must read as zero in the GEMMs below
+    if ((e = hipMemsetAsync(dQ2, 0, ((size_t)N2 * d + (size_t)(N1 + N2) * ZC) * sizeof(float), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(dX1, 0, (size_t)N1 * d * sizeof(float), st)) != hipSuccess) return (int)e;
+    const int np = (maxn + 31) & ~31;
+    const int ldc = np + 1;
+    const size_t lds = co_lds_floats(np, ldc, H, true) * sizeof(float);
+    BMP_REQUIRE(lds <= 160 * 1024);
+    int rc;
+    if ((rc = co_set_lds((const void*)k_coattn_bwd, 160 * 1024))) return rc;
+    CoArgs a; memset(&a, 0, sizeof(a));
+    a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
+    a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.ldc = ldc;
+    a.Cbuf = const_cast<float*>(Cbuf); a.H1 = const_cast<float*>(H1); a.H2 = const_cast<float*>(H2);
+    a.al1 = const_cast<float*>(al1); a.al2 = const_cast<float*>(al2);
+    a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
+    hipLaunchKernelGGL(k_coattn_bwd, dim3(B), dim3(256), lds, st, a);
+    BMP_LAUNCH_CHECK();
+    {   // dX1 += dZ1 . ZW1   (K = ZC)
+        RGArgs g; memset(&g, 0, sizeof(g));
+        g.s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};
+        g.nsrc = 1; g.Nout = d; g.Y = dX1; g.ldy = d; g.accumulate = 1;
+        if ((rc = bmp_launch_rowgemm(g, n_tiles1, BMP_EPI_GENERIC, st))) return rc;
+    }
+    {   // dX2 = dQ2 . W + dZ2 . ZW2
+        RGArgs g; memset(&g, 0, sizeof(g));
+        g.s[0] = RGSrc{dQ2, nullptr, Wb, d, 0, d, d};
+        g.s[1] = RGSrc{dZ2, nullptr, ZW2, ZC, 0, d, ZC};
+        g.nsrc = 2; g.Nout = d; g.Y = dX2; g.ldy = d;
+        if ((rc = bmp_launch_rowgemm(g, n_tiles2, BMP_EPI_GENERIC, st))) return rc;
+    }
+    {
+        WGArgs g{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0};
+        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
+        WGArgs g1{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0};
+        if ((rc = bmp_launch_wgrad(g1, slab, st))) return rc;
+        WGArgs g2{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0};
+        if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
+    }
+    if ((rc = bmp_launch_colsum(dZ1, ZC, N1, ZC, dzb, 0, slab, st))) return rc;
+    if ((rc = bmp_launch_colsum(dZ2, ZC, N2, ZC, dzb, 1, slab, st))) return rc;
+    return bmp_launch_colsum(dpart, 2 * H + 1, B, 2 * H + 1, dwa, 0, slab, st);
+}
