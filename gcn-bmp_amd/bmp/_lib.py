@@ -20,6 +20,8 @@ _P, _I, _Z = c_void_p, c_int, c_size_t
 SIGNATURES = {
     "bmp_version": (_I, []),
     "bmp_tile_rows": (_I, []),
+    "bmp_prof_start": (_I, [_I]),
+    "bmp_prof_stop": (_I, [_P]),
     "bmp_embed_fwd": (_I, [_P, _P, _I, _I, _P, _P]),
     "bmp_embed_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "bmp_msg_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),

@@ -154,6 +154,10 @@ int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st) {
         BMP_REQUIRE(((uintptr_t)a.s[s].X & 15) == 0);
         if (a.s[s].X2) BMP_REQUIRE((a.s[s].ldx2 & 3) == 0 && ((uintptr_t)a.s[s].X2 & 15) == 0);
     }
+    double ksum = 0;
+    for (int s = 0; s < a.nsrc; ++s) ksum += a.s[s].K;
+    const double rows = (double)n_tiles * BMP_R;
+    BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * ksum * a.Nout, 4.0 * rows * (ksum + a.Nout), st);
     switch (epi) {
         case BMP_EPI_GENERIC: return launch_rowgemm_epi<BMP_EPI_GENERIC>(a, n_tiles, st);
         case BMP_EPI_GRU_OUT: return launch_rowgemm_epi<BMP_EPI_GRU_OUT>(a, n_tiles, st);
@@ -275,10 +279,13 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     wgrad_plan(a.N, a.K, a.Nn, mb, nb, S, rps);
     WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws};
     dim3 grid((a.K + 64 * mb - 1) / (64 * mb), (a.Nn + 64 * nb - 1) / (64 * nb), S);
+    {
+    BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st);
     if (mb == 2 && nb == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, dim3(256), 0, st, k);
     else if (mb == 2) hipLaunchKernelGGL((k_wgrad<2, 1>), grid, dim3(256), 0, st, k);
     else if (nb == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((k_wgrad<1, 1>), grid, dim3(256), 0, st, k);
+    }
     BMP_LAUNCH_CHECK();
     const size_t total = (size_t)a.K * a.Nn;
     int blocks = (int)((total + 255) / 256);

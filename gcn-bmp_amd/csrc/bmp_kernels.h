@@ -74,3 +74,17 @@ int bmp_launch_gather_fwd(const float* x, int ldx, int N, int d, const int* ptr,
 // backward gather (transposed CSR): dx[j, k] (=|+=) sum_{(i,e) in csrT(j)} val * dagg[i, e*d + k]
 int bmp_launch_gather_bwd(const float* dagg, int N, int d, const int* ptrT, const int* colT, const float* valT,
                           float* dx, int lddx, int accumulate, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-kernel-class timing with HIP events (bench.py's roofline leg).  Off by default;
+// the only process-global state in the library.  While a class is armed, every launch of that
+// class is bracketed by two events on the launch stream.
+// ---------------------------------------------------------------------------------------------
+enum { BMP_KCLS_ROWGEMM = 1, BMP_KCLS_WGRAD = 2, BMP_KCLS_GATHER = 3, BMP_KCLS_COATTN = 4, BMP_KCLS_STEP_FWD = 5,
+       BMP_KCLS_STEP_BWD = 6 };
+struct BmpProfScope {
+    BmpProfScope(int kclass, double flops, double bytes, hipStream_t st);
+    ~BmpProfScope();
+    int slot;
+    hipStream_t st;
+};

@@ -1,0 +1,48 @@
+// HIP-event timing of one kernel class (see bmp_kernels.h).  Diagnostic only.
+#include <vector>
+#include "bmp_kernels.h"
+
+namespace {
+struct Rec { hipEvent_t a, b; double flops, bytes; };
+int g_cls = 0;
+std::vector<Rec> g_recs;
+}  // namespace
+
+BmpProfScope::BmpProfScope(int kclass, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
+    if (g_cls == 0 || kclass != g_cls) return;
+    Rec r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    r.flops = flops; r.bytes = bytes;
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+}
+
+BmpProfScope::~BmpProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, st);
+}
+
+extern "C" int bmp_prof_start(int kclass) {
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_recs.clear();
+    g_cls = kclass;
+    return 0;
+}
+
+// Waits for the recorded launches, returns their count; sums go to out[0] = total ms,
+// out[1] = total flops, out[2] = total bytes (as given by the launchers: executed, all rows).
+extern "C" int bmp_prof_stop(double* out) {
+    double ms = 0, fl = 0, by = 0;
+    int n = 0;
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms += t; fl += r.flops; by += r.bytes; ++n;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    g_cls = 0;
+    out[0] = ms; out[1] = fl; out[2] = by;
+    return n;
+}

@@ -33,6 +33,13 @@ enum { BMP_ACT_NONE = 0, BMP_ACT_SIGMOID = 1, BMP_ACT_TANH = 2, BMP_ACT_RELU = 3
 int bmp_version(void);
 int bmp_tile_rows(void);
 
+/* Diagnostic (bench.py roofline leg; no reference counterpart): bracket every launch of one
+ * kernel class with HIP events on its launch stream.  kclass: 1 row GEMM, 2 weight-gradient
+ * GEMM, 3 gather, 4 co-attention pair kernel, 5/6 fused GGNN step fwd/bwd.  bmp_prof_stop waits
+ * for the launches, returns their count and fills out[0..2] = total ms, executed flops, bytes. */
+int bmp_prof_start(int kclass);
+int bmp_prof_stop(double* out);
+
 /* EmbedAtomID lookup -- chainer_chemistry EmbedAtomID used at models/ggnn.py:85,603
  * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:].  bwd accumulates INTO dW [V x d]. */
 int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float* out, bmp_stream_t stream);

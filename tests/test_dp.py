@@ -1,0 +1,120 @@
+"""Data-parallel step plumbing on CPU: world_size-2 gloo processes, one all-reduce per step.
+
+KAT (viii) of SURVEY.md section 7: the all-reduced gradient equals the mean of the per-shard
+gradients, parameters stay bit-identical across ranks after Adam steps, and FlatAdam follows
+Chainer's Adam update rule (train_ddi_modify.py:289).  The model here is the torch-only MLP
+link predictor (the HIP encoder needs a GPU); the DP code path is model-agnostic.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bmp.dp import FlatAdam, shard
+from bmp.mlp import MLP
+from bmp.predictor import sigmoid_cross_entropy
+
+
+def _data():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 16, generator=g)
+    t = (torch.rand(64, 1, generator=g) < 0.3).int()
+    return x, t
+
+
+def _model():
+    torch.manual_seed(5)
+    return MLP(1, (8, 4), in_dim=16)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, t = _data()
+        model = _model()
+        if rank == 1:                                # ranks start different; broadcast must fix it
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)
+        opt = FlatAdam(model, alpha=1e-2, weight_decay_rate=1e-3)
+        opt.broadcast_parameters(0)
+        sl = shard(64, rank, world)
+        grads = None
+        for step in range(3):
+            opt.zero_grad()
+            loss = sigmoid_cross_entropy(model(x[sl]), t[sl])
+            loss.backward()
+            opt.all_reduce_grads()
+            if step == 0:
+                grads = opt.grad.clone()
+            opt.step()
+        out[rank] = (grads.numpy(), opt.flat.detach().clone().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_mean_of_shards():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g0, p0 = out[0]
+    g1, p1 = out[1]
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)          # bit-identical across ranks
+
+    # single-process reference: mean of the two shards' gradients, same Adam
+    x, t = _data()
+    model = _model()
+    ref = FlatAdam(model, alpha=1e-2, weight_decay_rate=1e-3)
+    first = None
+    for step in range(3):
+        acc = torch.zeros_like(ref.grad)
+        for r in range(world):
+            ref.zero_grad()
+            sigmoid_cross_entropy(model(x[shard(64, r, world)]), t[shard(64, r, world)]).backward()
+            acc += ref.grad
+        ref.grad.copy_(acc / world)
+        if step == 0:
+            first = ref.grad.clone()
+        ref.step()
+    assert np.allclose(g0, first.numpy(), rtol=1e-6, atol=1e-8)
+    assert np.allclose(p0, ref.flat.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_flat_adam_is_chainer_adam():
+    from oracle.ref_cpu import chainer_adam_step
+    model = _model()
+    opt = FlatAdam(model, alpha=3e-3, weight_decay_rate=1e-2)
+    params = [p.detach().clone() for p in model.parameters()]
+    state = [dict(m=torch.zeros_like(p), v=torch.zeros_like(p)) for p in params]
+    g = torch.Generator().manual_seed(1)
+    for t in range(1, 4):
+        grads = [torch.randn(p.shape, generator=g) for p in params]
+        for p, gr in zip(model.parameters(), grads):
+            p.grad.copy_(gr)
+        opt.step()
+        chainer_adam_step(params, grads, state, t, alpha=3e-3, weight_decay_rate=1e-2)
+    for p, q in zip(model.parameters(), params):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+
+
+def test_parameters_are_views_of_the_flat_buffer():
+    model = _model()
+    opt = FlatAdam(model)
+    base = opt.flat.data_ptr()
+    off = 0
+    for p in model.parameters():
+        assert p.data_ptr() == base + 4 * off and p.grad.data_ptr() == opt.grad.data_ptr() + 4 * off
+        off += p.numel()
+    assert off == opt.flat.numel()
+
+
+def test_shard_partitions_the_batch():
+    assert [shard(8192, r, 8) for r in range(8)] == [slice(1024 * r, 1024 * (r + 1)) for r in range(8)]

@@ -54,7 +54,10 @@ def test_nie_coattention_op(pairs, d, o, act):
     # rows that belong to no molecule get no gradient in either implementation
     close(Xd.grad, Xr.grad, "dX")
     for name, gr in grad_dict(att).items():
-        close(gr, p[name].grad, f"grad {name}")
+        # with the identity activation the softmaxes are shift invariant, so d/d(energy bias) is
+        # analytically 0: compare it on the scale of the other energy-layer gradients
+        floor = p["energy_layer/V1"].grad.abs().max().item() if name == "energy_layer/b" else 1e-6
+        close(gr, p[name].grad, f"grad {name}", floor=floor)
 
 
 @pytest.mark.parametrize("d,nl,tying", [(16, 2, True), (128, 4, True), (32, 3, False)])
