@@ -58,7 +58,8 @@ def cpu_baseline(store, idx1, idx2, label, seconds=12.0):
     (train_ddi_modify.py:196), for about `seconds` of wall time."""
     from oracle import ref_cpu as O_
     from bmp import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box exposes all host cores but grants a 16-core share per GPU: more threads only thrash
+    torch.set_num_threads(min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
     p = O_.make_pair_params(777, hidden_dim=D, out_dim=O, n_layers=T_STEPS, attn="nie", head=HEAD, dtype=torch.float32,
                             bias_scale=0.0)
     names = sorted(p)

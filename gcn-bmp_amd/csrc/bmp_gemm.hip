@@ -242,14 +242,28 @@ __global__ __launch_bounds__(256) void k_wgrad(WGKArgs a) {
 }
 
 // out[i, j] (=|+=) sum_s slab[s][i][j]
-__global__ void k_reduce_slabs(const float* __restrict__ slab, int S, int K, int Nn, float* out, int ldo, int accumulate) {
+// 64 elements x 4 slab lanes per workgroup; fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab, int S, int K, int Nn, float* out,
+                                                      int ldo, int accumulate) {
+    __shared__ float red[4][64];
     const size_t total = (size_t)K * Nn;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+        const size_t idx = base + c;
         float v = 0.f;
-        for (int s = 0; s < S; ++s) v += slab[(size_t)s * total + idx];
-        const int i = (int)(idx / Nn), j = (int)(idx % Nn);
-        float* o = out + (size_t)i * ldo + j;
-        *o = accumulate ? (*o + v) : v;
+        if (idx < total) {
+#pragma unroll 8
+            for (int s = g; s < S; s += 4) v += slab[(size_t)s * total + idx];
+        }
+        red[g][c] = v;
+        __syncthreads();
+        if (g == 0 && idx < total) {
+            v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            const int i = (int)(idx / Nn), j = (int)(idx % Nn);
+            float* o = out + (size_t)i * ldo + j;
+            *o = accumulate ? (*o + v) : v;
+        }
+        __syncthreads();
     }
 }
 
@@ -257,8 +271,8 @@ static void wgrad_plan(int N, int K, int Nn, int& mb, int& nb, int& S, int& rps)
     mb = K > 32 ? 2 : 1;
     nb = Nn > 32 ? 2 : 1;
     const int tiles = ((K + 64 * mb - 1) / (64 * mb)) * ((Nn + 64 * nb - 1) / (64 * nb));
-    int want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU in total
-    int max_s = N / 64;                               // at least 64 rows per split
+    int want = (512 + tiles - 1) / tiles;             // ~2 workgroups per CU in total
+    int max_s = N / 128;                              // at least 128 rows per split
     if (max_s < 1) max_s = 1;
     S = want < max_s ? want : max_s;
     if (S < 1) S = 1;
@@ -288,8 +302,8 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     }
     BMP_LAUNCH_CHECK();
     const size_t total = (size_t)a.K * a.Nn;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((total + 63) / 64);
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, ws, S, a.K, a.Nn, a.out, a.ldo, a.accumulate);
     BMP_LAUNCH_CHECK();
     return 0;
@@ -314,9 +328,9 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, in
 }
 
 static void colsum_plan(int N, int& S, int& rps) {
-    S = N / 256;
+    S = N / 512;
     if (S < 1) S = 1;
-    if (S > 256) S = 256;
+    if (S > 128) S = 128;
     rps = (N + S - 1) / S;
     S = (N + rps - 1) / rps;
 }
@@ -333,7 +347,7 @@ int bmp_launch_colsum(const float* dY, int ldy, int N, int Nn, float* out, int a
     colsum_plan(N, S, rps);
     hipLaunchKernelGGL(k_colsum, dim3((Nn + 63) / 64, S), dim3(256), 0, st, dY, ldy, N, Nn, rps, ws);
     BMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((Nn + 255) / 256), dim3(256), 0, st, ws, S, 1, Nn, out, Nn, accumulate);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((Nn + 63) / 64), dim3(256), 0, st, ws, S, 1, Nn, out, Nn, accumulate);
     BMP_LAUNCH_CHECK();
     return 0;
 }
