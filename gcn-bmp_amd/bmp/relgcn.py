@@ -1,0 +1,190 @@
+"""RelGCN encoder and the modular GGNN built from update/readout blocks, with the reference's
+signatures: ``models.relgcn.RelGCN`` (models/relgcn.py:31-73), ``models.update.RelGCNUpdate``
+(models/update/relgcn_update.py:12-44), ``models.update.GGNNUpdate``
+(models/update/ggnn_update.py:15-65), ``models.readout.GGNNReadout``
+(models/readout/ggnn_readout.py:13-57) and ``models.models.ggnn.GGNN`` (models/models/ggnn.py:26-108).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import functional as Fn
+from .ggnn import (EmbedID, GRU, Linear, MAX_ATOMIC_NUM, NUM_EDGE_TYPE, PackedAtoms, as_packed,
+                   message_kernel_weights)
+from .packed import PackedMolBatch
+
+
+def rescale_adj(pb: PackedMolBatch) -> PackedMolBatch:
+    """models/relgcn.py:20-28 on the packed batch: every bond value is divided by the SOURCE
+    atom's degree (sum of adj over bond types and destination rows; 0 -> 1).  Index work +
+    one exact fp32 reciprocal-multiply per bond, same rounding as the reference's adj * (1/deg)."""
+    if "rescaled" in pb._cache:
+        return pb._cache["rescaled"]
+    N = pb.n_rows
+    src = (pb.csr_col >> 2).long()
+    deg = torch.zeros(N, dtype=torch.float32, device=pb.device).index_add_(0, src, pb.csr_val)
+    inv = 1.0 / torch.where(deg != 0, deg, torch.ones_like(deg))
+    rowT = torch.repeat_interleave(torch.arange(N, device=pb.device), (pb.csrT_ptr[1:] - pb.csrT_ptr[:-1]).long())
+    out = dataclasses.replace(pb, csr_val=(pb.csr_val * inv[src]).contiguous(),
+                              csrT_val=(pb.csrT_val * inv[rowT]).contiguous(), _cache={})
+    pb._cache["rescaled"] = out
+    return out
+
+
+class RelGCNUpdate(nn.Module):
+    def __init__(self, in_channels, out_channels, num_edge_type=4):
+        super().__init__()
+        if num_edge_type != NUM_EDGE_TYPE:
+            raise NotImplementedError("num_edge_type must be 4")
+        if in_channels % 8 or out_channels % 8:
+            raise ValueError("channel counts must be multiples of 8 for the MFMA kernels")
+        self.graph_linear_self = Linear(in_channels, out_channels)
+        self.graph_linear_edge = Linear(in_channels, out_channels * num_edge_type)
+        self.num_edge_type, self.in_channels, self.out_channels = num_edge_type, in_channels, out_channels
+
+    def forward(self, h, pb, act="identity"):
+        """hs + sum_e adj_e (W_e h + b_e) (relgcn_update.py:24-44); ``act`` lets the caller fuse the
+        tanh of models/relgcn.py:71 into the same kernel."""
+        WT, bE = message_kernel_weights(self.graph_linear_edge)
+        return Fn.MsgFn.apply(h, WT, bE, self.graph_linear_self.W.t(), self.graph_linear_self.b, pb, Fn.ACT[act])
+
+
+class GGNNUpdate(nn.Module):
+    """One message linear + its OWN stateful GRU (ggnn_update.py:25-29)."""
+
+    def __init__(self, hidden_dim=16, num_edge_type=4):
+        super().__init__()
+        if num_edge_type != NUM_EDGE_TYPE:
+            raise NotImplementedError("num_edge_type must be 4")
+        self.graph_linear = Linear(hidden_dim, num_edge_type * hidden_dim)
+        self.update_layer = GRU(2 * hidden_dim, hidden_dim)
+        self.num_edge_type = num_edge_type
+        self._calls = 0
+
+    def reset_state(self):
+        self._calls = 0
+
+    def forward(self, h, pb):
+        WT, bE = message_kernel_weights(self.graph_linear)
+        m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
+        first = self._calls == 0
+        AT, UcT, b = self.update_layer.kernel_weights(first)
+        self._calls += 1
+        return Fn.GRUFn.apply(h, m, AT, UcT, b, pb, first)
+
+
+class GGNNReadout(nn.Module):
+    def __init__(self, out_dim, hidden_dim=16, nobias=False, activation="identity", activation_agg="identity",
+                 in_dim: Optional[int] = None):
+        """``in_dim`` replaces Chainer's lazy GraphLinear(None, out_dim): hidden_dim when called
+        without h0, 2*hidden_dim with h0."""
+        super().__init__()
+        in_dim = hidden_dim if in_dim is None else in_dim
+        self.i_layer = Linear(in_dim, out_dim, nobias=nobias)
+        self.j_layer = Linear(in_dim, out_dim, nobias=nobias)
+        self.out_dim, self.hidden_dim, self.nobias = out_dim, hidden_dim, nobias
+        self.activation, self.activation_agg = activation, activation_agg
+
+    def forward(self, h, pb, h0=None, row_w=None):
+        WT = torch.cat((self.i_layer.W.t(), self.j_layer.W.t()), dim=1).contiguous()
+        b = None if self.nobias else torch.cat((self.i_layer.b, self.j_layer.b))
+        if row_w is not None:
+            pb = dataclasses.replace(pb, row_w=row_w, _cache={})
+        g = Fn.ReadoutFn.apply(h, h0, WT, b, pb, Fn.ACT[self.activation])
+        if self.activation_agg == "tanh":
+            g = torch.tanh(g)
+        elif self.activation_agg == "sigmoid":
+            g = torch.sigmoid(g)
+        elif self.activation_agg == "relu":
+            g = torch.relu(g)
+        return g
+
+
+class RelGCN(nn.Module):
+    def __init__(self, out_channels=64, num_edge_type=4, ch_list=None, n_atom_types=MAX_ATOMIC_NUM, input_type='int',
+                 scale_adj=None):
+        super().__init__()
+        if ch_list is None:
+            ch_list = [16, 128, 64]                                            # models/relgcn.py:37
+        if input_type != 'int':
+            if input_type == 'float':
+                raise NotImplementedError("input_type='float' is not supported")
+            raise ValueError("[ERROR] Unexpected value input type={}".format(input_type))
+        self.embed = EmbedID(out_size=ch_list[0], in_size=n_atom_types)
+        self.rgcn_convs = nn.ModuleList([RelGCNUpdate(ch_list[i], ch_list[i + 1], num_edge_type)
+                                         for i in range(len(ch_list) - 1)])
+        self.rgcn_readout = GGNNReadout(out_dim=out_channels, hidden_dim=ch_list[-1], nobias=True, activation="tanh")
+        self.input_type, self.scale_adj = input_type, scale_adj
+        self.out_dim, self.hidden_dim, self.n_layers = out_channels, ch_list[-1], len(ch_list) - 1
+        self.atoms = None
+
+    def forward(self, h, adj=None):
+        """models/relgcn.py:61-73."""
+        pb = as_packed(h, adj, self.embed.W.device)
+        x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
+        pbs = rescale_adj(pb) if self.scale_adj else pb
+        for conv in self.rgcn_convs:
+            x = conv(x, pbs, act="tanh")                                       # :70-71
+        self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
+        return self.rgcn_readout(x, pb)
+
+    def get_atom_array(self):
+        """Not in the reference: last-layer atom states, so that RelGCN composes
+        with the co-attention as BASELINE.json config 3 requires."""
+        assert self.atoms is not None
+        return self.atoms
+
+
+class GGNNModular(nn.Module):
+    """models/models/ggnn.py:26-108: GGNN assembled from GGNNUpdate / GGNNReadout blocks.  Each
+    update layer owns its GRU, so with weight_tying=False every GRU call is a first call."""
+
+    def __init__(self, out_dim, hidden_dim=16, n_layers=4, n_atom_types=MAX_ATOMIC_NUM, concat_hidden=False,
+                 weight_tying=True, activation="identity", num_edge_type=4):
+        super().__init__()
+        n_readout_layer = n_layers if concat_hidden else 1
+        n_message_layer = 1 if weight_tying else n_layers
+        self.embed = EmbedID(out_size=hidden_dim, in_size=n_atom_types)
+        self.update_layers = nn.ModuleList([GGNNUpdate(hidden_dim, num_edge_type) for _ in range(n_message_layer)])
+        self.readout_layers = nn.ModuleList([
+            GGNNReadout(out_dim=out_dim, hidden_dim=hidden_dim, activation=activation, activation_agg=activation,
+                        in_dim=2 * hidden_dim) for _ in range(n_readout_layer)])
+        self.out_dim, self.hidden_dim, self.n_layers = out_dim, hidden_dim, n_layers
+        self.concat_hidden, self.weight_tying = concat_hidden, weight_tying
+        self.atoms = None
+
+    def reset_state(self):
+        for u in self.update_layers:
+            u.reset_state()
+
+    def forward(self, atom_array, adj=None, is_real_node=None):
+        pb = as_packed(atom_array, adj, self.embed.W.device)
+        row_w = None
+        if is_real_node is not None:
+            # mask (mb, A) -> per-row weight: a virtual row carries the sum of its positions' masks
+            if pb.dense_map is None:
+                raise NotImplementedError("is_real_node needs the dense input form")
+            m = torch.as_tensor(np.asarray(is_real_node), dtype=torch.float32, device=pb.device)
+            row_w = torch.zeros(pb.n_rows, device=pb.device).index_add_(0, pb.dense_map.reshape(-1), m.reshape(-1))
+        self.reset_state()                                                       # models/models/ggnn.py:87
+        h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
+        h0 = h
+        g_list = []
+        for step in range(self.n_layers):
+            li = 0 if self.weight_tying else step
+            h = self.update_layers[li](h, pb)
+            if self.concat_hidden:
+                g_list.append(self.readout_layers[step](h, pb, h0, row_w))
+        self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
+        if self.concat_hidden:
+            return torch.cat(g_list, dim=1)
+        return self.readout_layers[0](h, pb, h0, row_w)
+
+    def get_atom_array(self):
+        assert self.atoms is not None
+        return self.atoms
