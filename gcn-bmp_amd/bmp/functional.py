@@ -152,6 +152,58 @@ class GRUFn(Function):
         return dh, dm, dAT, dUcT, db, None, None
 
 
+def step_supported(d: int) -> bool:
+    return bool(_lib.lib().bmp_ggnn_step_supported(int(d)))
+
+
+class GGNNStepFn(Function):
+    """One whole propagation step (message + GRU) as ONE fused kernel per tile
+    (models/ggnn.py:215-263).  Same weight layouts as MsgFn / GRUFn."""
+
+    @staticmethod
+    def forward(ctx, h, WT, bE, AT, UcT, b, pb, first):
+        L = _lib.lib()
+        require_rows(h, "step: h")
+        _check_pb(pb, h)
+        N, d = h.shape
+        if tuple(WT.shape) != (4 * d, d) or tuple(bE.shape) != (4, d) or tuple(AT.shape) != (2 * d, 3 * d) \
+                or tuple(UcT.shape) != (d, d) or tuple(b.shape) != (3 * d,):
+            raise ValueError("step: weight shapes do not match h")
+        WT, bE, AT, UcT, b = WT.contiguous(), bE.contiguous(), AT.contiguous(), UcT.contiguous(), b.contiguous()
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
+        m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
+        check(L.bmp_ggnn_step_fwd(ptr(h), pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+                                  ptr(WT), ptr(bE), ptr(AT), ptr(UcT), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout),
+                                  stream()), "bmp_ggnn_step_fwd")
+        ctx.save_for_backward(h, WT, AT, UcT, m, rz, c)
+        ctx.pb, ctx.first = pb, int(first)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dhout):
+        L = _lib.lib()
+        h, WT, AT, UcT, m, rz, c = ctx.saved_tensors
+        pb, first = ctx.pb, ctx.first
+        N, d = h.shape
+        dev = h.device
+        dhout = dhout.contiguous()
+        Wnat, A, Uc = WT.t().contiguous(), AT.t().contiguous(), UcT.t().contiguous()
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        dh, gda = f(N, d), f(N, 7 * d)
+        check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
+                                  ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(A), ptr(Uc), ptr(dh), ptr(gda),
+                                  stream()), "bmp_ggnn_step_bwd")
+        o1, o2, dUcT, cs = f(d, 7 * d), f(d, 3 * d), f(d, d), f(7 * d)
+        nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
+        ws = _ws(nws, dev)
+        check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(o1), ptr(o2), ptr(dUcT), ptr(cs),
+                                    0, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+        dWT = o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)      # [k][e*d+c] -> [e*d+k][c]
+        dbE = cs[:4 * d].reshape(4, d)
+        dAT = torch.cat((o1[:, 4 * d:], o2), dim=0)
+        return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None
+
+
 class ReadoutFn(Function):
     """Gated-sum readout (models/ggnn.py:333-341; models/readout/ggnn_readout.py:42-57).
     WT [(d+d0) x 2o] cols [i|j]; b [2o] or None; h0 may be None."""

@@ -142,6 +142,7 @@ class GGNN(nn.Module):
         self.i_layers = nn.ModuleList([Linear(2 * hidden_dim, out_dim) for _ in range(self.n_readout_layer)])
         self.j_layers = nn.ModuleList([Linear(hidden_dim, out_dim) for _ in range(self.n_readout_layer)])
         self.atoms = None
+        self.fused = True      # use the fused per-tile step kernel where the width allows (64, 128)
 
     # models/ggnn.py:333-341: i sees [h, h0], j sees h only -> j's h0 rows are zero in the kernel layout
     def _readout_weights(self, k: int):
@@ -164,18 +165,22 @@ class GGNN(nn.Module):
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)                 # :603
         h0 = h                                                          # :612
         later = None
+        fused = self.fused and Fn.step_supported(self.hidden_dim)
         g_list = []
         for step in range(self.n_layers):                               # :616
             li = 0 if self.weight_tying else step                       # :220
             WT, bE = message_kernel_weights(self.message_layers[li])
-            m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
             if step == 0:
                 AT, UcT, b = self.update_layer.kernel_weights(first=True)
             else:
                 if later is None:
                     later = self.update_layer.kernel_weights(first=False)
                 AT, UcT, b = later
-            h = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, step == 0)        # :254-262, state reset at :599
+            if fused:       # message + GRU in one kernel per tile, atom states resident in LDS
+                h = Fn.GGNNStepFn.apply(h, WT, bE, AT, UcT, b, pb, step == 0)
+            else:
+                m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
+                h = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, step == 0)    # :254-262, state reset at :599
             if self.concat_hidden:
                 g_list.append(self.readout(h, h0, pb, step))
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)     # models/ggnn_att.py:651

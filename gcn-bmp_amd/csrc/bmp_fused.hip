@@ -1,0 +1,476 @@
+// Fused GGNN propagation step for gfx950: message (per-bond-type gather-sum + linear) and GRU node
+// update in ONE kernel per 128-row tile, forward and backward  (models/ggnn.py:215-263).
+//
+// A tile holds whole molecules (bmp/packed.py), so the neighbour gather is tile-local: the tile's
+// atom states live in LDS for the whole step and never round-trip through HBM between the message
+// linear, the three gate GEMMs and the candidate GEMM.  Per tile and step the forward reads h once
+// (64 KB at d=128) and writes m, r|z, c, h' (the backward's inputs); weights (720 KB fp32 at d=128)
+// stream from L2 into MFMA B registers, double-buffered in registers one k-step ahead.
+//
+//   workgroup = 512 threads = 8 waves (2 per SIMD), LDS = two [128 x (D+4)] f32 tiles (135 KB at D=128)
+//   wave (wr, wc) owns rows [wr*RB*32, +RB*32) x cols [wc*32, +32) of every [128 x D] result,
+//   D = 128: 2 x 4 waves, RB = 2;  D = 64: 4 x 2 waves, RB = 1.
+//   dense work: v_mfma_f32_32x32x2_f32 (exact f32); K order per lane: four consecutive k per 16-B read.
+#include <string.h>
+#include "bmp_kernels.h"
+
+#define FZ_R 128
+
+struct StepArgs {
+    // graph
+    const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
+    int first;
+    // forward
+    const float* h;                 // [N x D] step input
+    const float* WT;                // [4D x D]  message weights, K-major (row e*D + k, col c)
+    const float* bE;                // [4 x D]
+    const float* AT;                // [2D x 3D] gate weights K-major, rows [h ; m], cols [r | z | c]
+    const float* UcT;               // [D x D]
+    const float* b;                 // [3D]
+    float* m; float* rz; float* c; float* hout;
+    // backward
+    const float* dhout;             // [N x D]
+    const float* Wnat;              // [D x 4D]  (= WT^T: row c, col e*D + k)
+    const float* A;                 // [3D x 2D] (= AT^T)
+    const float* Uc;                // [D x D]   (= UcT^T, reference layout)
+    float* dh;                      // [N x D]
+    float* gda;                     // [N x 7D]: G (4D: gathered dm per bond type) | da_r | da_z | da_c
+};
+
+// acc[nb][rb] += A(rows of this wave, K) . B_nb(K, 32 cols)   with A in LDS, B streamed from global.
+//   As_wave = &tile[(wave_row0 + (lane & 31)) * LD + 4 * (lane >> 5)]
+//   Bp[nb]  = B_nb + 4 * (lane >> 5) * ldw[nb] + col      (col = this lane's output column)
+template <int NB, int RB>
+__device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
+                                         const int (&ldw)[NB], int K) {
+    float bc[NB][4], bn[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bc[nb][t] = Bp[nb][(size_t)t * ldw[nb]];
+#pragma unroll 2
+    for (int kk = 0; kk < K; kk += 8) {
+        if (kk + 8 < K) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bn[nb][t] = Bp[nb][(size_t)(kk + 8 + t) * ldw[nb]];
+        }
+        f32x4 av[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) av[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + kk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(av[rb][t], bc[nb][t], acc[nb][rb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bc[nb][t] = bn[nb][t];
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+}
+
+// Tile-local neighbour gather for one bond type: dst[row, :] = sum over CSR entries of `row` with type e of
+// val * src_tile[col_local, :].  4 threads per row, D/4 columns each.  Returns (per thread) whether it saw a
+// matching entry; *wsum gets the row's weighted degree for that type.
+template <int D>
+__device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_tile, int LD, const int* ptr, const int* col,
+                                            const float* val, int row0, int e, float* wsum) {
+    constexpr int F = D / 16;                 // float4 per thread
+    const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+    f32x4 acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wd = 0.f;
+    bool any = false;
+    const int e0 = ptr[row0 + row], e1 = ptr[row0 + row + 1];
+    for (int ed = e0; ed < e1; ++ed) {
+        const int cv = col[ed];
+        if ((cv & 3) == e) {
+            const float v = val[ed];
+            const float* s = src_tile + ((cv >> 2) - row0) * LD + q * (D / 4);
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += *(const f32x4*)(s + 4 * f) * v;
+            wd += v;
+            any = true;
+        }
+    }
+    float* o = dst_tile + row * LD + q * (D / 4);
+#pragma unroll
+    for (int f = 0; f < F; ++f) *(f32x4*)(o + 4 * f) = acc[f];
+    *wsum = wd;
+    return any;
+}
+
+// Accumulator-layout access to a row-major [rows x LDC] f32 array through a buffer resource: all 16*RB
+// positions of a wave share ONE 32-bit voffset VGPR (the lane's (row, col) byte offset); the per-register
+// row offset is a compile-time soffset/immediate.  (Plain pointers cost a 64-bit address pair per element
+// here, which the register allocator keeps alive across the MFMA phases and spills.)
+struct AccBuf {
+    __amdgpu_buffer_rsrc_t rs;
+    int vo;
+};
+template <int LDC>
+__device__ __forceinline__ AccBuf acc_buf(const float* base, int tile_row0, int lane_row, int col) {
+    AccBuf b;
+    b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)tile_row0 * LDC), 0, 0x7FFFFFFF, 0x00020000);
+    b.vo = (lane_row * LDC + col) * 4;
+    return b;
+}
+template <int LDC>
+__device__ __forceinline__ float acc_ld(const AccBuf& b, int rb, int reg, int coff = 0) {
+    const int so = ((rb * 32 + (reg & 3) + 8 * (reg >> 2)) * LDC + coff) * 4;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rs, b.vo, so, 0));
+}
+template <int LDC>
+__device__ __forceinline__ void acc_st(const AccBuf& b, int rb, int reg, float v, int coff = 0) {
+    const int so = ((rb * 32 + (reg & 3) + 8 * (reg >> 2)) * LDC + coff) * 4;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.rs, b.vo, so, 0);
+}
+
+#define FZ_FOR_ACC _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)
+
+template <int D, bool FIRST>
+__global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
+    constexpr int LD = D + 4;
+    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Hs = lds;                         // [128 x LD]  h tile (whole step)
+    float* As = lds + FZ_R * LD;             // [128 x LD]  AGG_e -> M -> r*h
+    float* wds = As + FZ_R * LD;             // [128 x 4]   weighted degree per bond type
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wc = w % NCB, wr = w / NCB;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * FZ_R;
+    const int col = wc * 32 + l31;
+    const int wrow0 = wr * RB * 32;
+    const int lrow = wrow0 + 4 * hi;         // this lane's row for reg 0 of row block 0
+    const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
+    const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
+    float* Hl = Hs + lrow * LD + col;        // accumulator-layout views of the two LDS tiles
+    float* Al = As + lrow * LD + col;
+#define LOFF(rb, reg) (((rb) * 32 + ((reg) & 3) + 8 * ((reg) >> 2)) * LD)
+
+    // ---- h tile -> LDS ----
+    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+        const int r = idx / (D / 4), c4 = idx % (D / 4);
+        *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
+    }
+    __syncthreads();
+
+    // ---- message: m = sum_e AGG_e . W_e + wdeg_e * b_e   (models/ggnn.py:223-242) ----
+    f32x16 acc_m[1][RB];
+    zero_acc(acc_m[0]);
+    for (int e = 0; e < 4; ++e) {
+        float wd;
+        const bool mine = tile_gather<D>(Hs, As, LD, a.ptr, a.col, a.val, row0, e, &wd);
+        if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
+        const int any = __syncthreads_or(mine ? 1 : 0);
+        if (any) {
+            const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + col};
+            const int ldw[1] = {D};
+            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D);
+        }
+        __syncthreads();
+    }
+    // m -> LDS (A operand of the gates) and HBM (saved for the backward)
+    {
+        const AccBuf mo = acc_buf<D>(a.m, row0, lrow, col);
+        float be[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) be[e] = a.bE[e * D + col];
+        FZ_FOR_ACC {
+            const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+            const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
+            const float v = acc_m[0][rb][reg] + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
+            Al[LOFF(rb, reg)] = v;
+            acc_st<D>(mo, rb, reg, v);
+        }
+    }
+    __syncthreads();
+
+    // ---- gates: [r | z | c~] = [h, m] . AT   (chainer StatefulGRU) ----
+    f32x16 acc_g[3][RB];
+    zero_acc(acc_g[0]); zero_acc(acc_g[1]); zero_acc(acc_g[2]);
+    {
+        const int ldw3[3] = {3 * D, 3 * D, 3 * D};
+        const float* base_h = a.AT + (size_t)(4 * hi) * 3 * D + col;
+        const float* base_m = a.AT + (size_t)(D + 4 * hi) * 3 * D + col;
+        if (FIRST) {      // first call after reset: z and c only, no state terms
+            f32x16 g2[2][RB];
+            zero_acc(g2[0]); zero_acc(g2[1]);
+            const int ldw2[2] = {3 * D, 3 * D};
+            const float* const Bh[2] = {base_h + D, base_h + 2 * D};
+            const float* const Bm[2] = {base_m + D, base_m + 2 * D};
+            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D);
+            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { acc_g[1][rb] = g2[0][rb]; acc_g[2][rb] = g2[1][rb]; }
+        } else {
+            const float* const Bh[3] = {base_h, base_h + D, base_h + 2 * D};
+            const float* const Bm[3] = {base_m, base_m + D, base_m + 2 * D};
+            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D);
+            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D);
+        }
+    }
+    const float br = a.b[col], bz = a.b[D + col], bcn = a.b[2 * D + col];
+    {   // r, z in place; save them
+        const AccBuf rzo = acc_buf<2 * D>(a.rz, row0, lrow, col);
+        FZ_FOR_ACC {
+            const float zv = bmp_sigmoid(acc_g[1][rb][reg] + bz);
+            acc_g[1][rb][reg] = zv;
+            acc_st<2 * D>(rzo, rb, reg, zv, D);
+            if (!FIRST) {
+                const float rv = bmp_sigmoid(acc_g[0][rb][reg] + br);
+                acc_g[0][rb][reg] = rv;
+                acc_st<2 * D>(rzo, rb, reg, rv, 0);
+            }
+        }
+    }
+    if (!FIRST) {
+        __syncthreads();                     // every wave is done reading M
+        FZ_FOR_ACC { Al[LOFF(rb, reg)] = acc_g[0][rb][reg] * Hl[LOFF(rb, reg)]; }      // r * h
+        __syncthreads();
+        f32x16 gc[1][RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
+        const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + col};
+        const int ldu[1] = {D};
+        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
+    }
+    // ---- h' = z*c + (1-z)*h  (first call: z*c) ----
+    {
+        const AccBuf co = acc_buf<D>(a.c, row0, lrow, col);
+        const AccBuf ho = acc_buf<D>(a.hout, row0, lrow, col);
+        FZ_FOR_ACC {
+            const float cv = bmp_tanh(acc_g[2][rb][reg] + bcn);
+            const float zv = acc_g[1][rb][reg];
+            float hn = zv * cv;
+            if (!FIRST) hn += (1.f - zv) * Hl[LOFF(rb, reg)];
+            acc_st<D>(co, rb, reg, cv);
+            acc_st<D>(ho, rb, reg, hn);
+        }
+    }
+}
+
+// Backward of one step for one tile: all of the backward-data path (gate derivatives, the three
+// transposed gate GEMMs, the message-linear transpose and the transposed neighbour gather), and the
+// per-row pre-activation gradients [G | da] the weight-gradient GEMMs consume.
+template <int D, bool FIRST>
+__global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
+    constexpr int LD = D + 4;
+    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;                         // [128 x LD]  da_c -> da_r -> da_z -> dm
+    float* Ys = lds + FZ_R * LD;             // [128 x LD]  G_e (transposed gather of dm)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wc = w % NCB, wr = w / NCB;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * FZ_R;
+    const int col = wc * 32 + l31;
+    const int wrow0 = wr * RB * 32;
+    const int lrow = wrow0 + 4 * hi;
+    const float* Xw = Xs + (wrow0 + l31) * LD + 4 * hi;
+    const float* Yw = Ys + (wrow0 + l31) * LD + 4 * hi;
+    float* Xl = Xs + lrow * LD + col;
+    constexpr bool first = FIRST;
+
+    const AccBuf gi = acc_buf<D>(a.dhout, row0, lrow, col);
+    const AccBuf ci = acc_buf<D>(a.c, row0, lrow, col);
+    const AccBuf hin = acc_buf<D>(a.h, row0, lrow, col);
+    const AccBuf rzi = acc_buf<2 * D>(a.rz, row0, lrow, col);
+    const AccBuf go = acc_buf<7 * D>(a.gda, row0, lrow, col);
+
+    // ---- X = da_c = dh' * z * (1 - c^2);  dh accumulator starts at dh' * (1 - z) (0 on the first call) ----
+    f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
+    zero_acc(acc_x[0]); zero_acc(acc_x[1]);
+    FZ_FOR_ACC {
+        const float g = acc_ld<D>(gi, rb, reg);
+        const float z = acc_ld<2 * D>(rzi, rb, reg, D);
+        const float cv = acc_ld<D>(ci, rb, reg);
+        const float dac = g * z * (1.f - cv * cv);
+        if (!first) acc_x[0][rb][reg] = g * (1.f - z);
+        Xl[LOFF(rb, reg)] = dac;
+        acc_st<7 * D>(go, rb, reg, dac, 6 * D);
+    }
+    __syncthreads();
+
+    const float* const Ac_h = a.A + (size_t)(2 * D + 4 * hi) * 2 * D + col;
+    const float* const Az_h = a.A + (size_t)(D + 4 * hi) * 2 * D + col;
+    const float* const Ar_h = a.A + (size_t)(4 * hi) * 2 * D + col;
+    const int ld2[2] = {2 * D, 2 * D};
+    {   // [dh | dm] += da_c . A_c
+        const float* const Bc[2] = {Ac_h, Ac_h + D};
+        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D);
+    }
+    if (!first) {
+        f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
+        zero_acc(acc_d[0]);
+        {
+            const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + col};
+            const int ldu[1] = {D};
+            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D);
+        }
+        __syncthreads();                     // all waves done with da_c in X
+        // da_r = d(r*h) * h * r * (1-r) -> X ; dh += d(r*h) * r
+        FZ_FOR_ACC {
+            const float rv = acc_ld<2 * D>(rzi, rb, reg, 0);
+            const float hv = acc_ld<D>(hin, rb, reg);
+            const float drh = acc_d[0][rb][reg];
+            const float dar = drh * hv * rv * (1.f - rv);
+            acc_x[0][rb][reg] += drh * rv;
+            Xl[LOFF(rb, reg)] = dar;
+            acc_st<7 * D>(go, rb, reg, dar, 4 * D);
+        }
+        __syncthreads();
+        {   // X = da_r
+            const float* const Br[2] = {Ar_h, Ar_h + D};
+            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D);
+        }
+    }
+    __syncthreads();
+    // da_z = dh' * (c - h) * z * (1-z) -> X   (first call: h term absent)
+    FZ_FOR_ACC {
+        const float g = acc_ld<D>(gi, rb, reg);
+        const float z = acc_ld<2 * D>(rzi, rb, reg, D);
+        const float cv = acc_ld<D>(ci, rb, reg);
+        const float hv = first ? 0.f : acc_ld<D>(hin, rb, reg);
+        const float dz = g * (cv - hv) * z * (1.f - z);
+        Xl[LOFF(rb, reg)] = dz;
+        acc_st<7 * D>(go, rb, reg, dz, 5 * D);
+        if (first) acc_st<7 * D>(go, rb, reg, 0.f, 4 * D);          // da_r = 0
+    }
+    __syncthreads();
+    {
+        const float* const Bz[2] = {Az_h, Az_h + D};
+        tile_mma<2, RB>(acc_x, Xw, LD, Bz, ld2, D);
+    }
+    __syncthreads();                         // all waves done with X
+    // ---- X <- dm ----
+    FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_x[1][rb][reg]; }
+    __syncthreads();
+
+    // ---- message backward: G_e = gather^T_e(dm) ; dh += G_e . W_e^T ----
+    f32x16 acc_h[1][RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc_h[0][rb] = acc_x[0][rb];
+    for (int e = 0; e < 4; ++e) {
+        float wd;
+        const bool mine = tile_gather<D>(Xs, Ys, LD, a.ptr, a.col, a.val, row0, e, &wd);
+        {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
+            const int row = tid >> 2, q = tid & 3;
+            const float* s = Ys + row * LD + q * (D / 4);
+            float* o = a.gda + (size_t)(row0 + row) * 7 * D + e * D + q * (D / 4);
+#pragma unroll
+            for (int f = 0; f < D / 16; ++f) *(f32x4*)(o + 4 * f) = *(const f32x4*)(s + 4 * f);
+        }
+        const int any = __syncthreads_or(mine ? 1 : 0);
+        if (any) {
+            const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + e * D + col};
+            const int ldw[1] = {4 * D};
+            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D);
+        }
+        __syncthreads();
+    }
+    {
+        const AccBuf dho = acc_buf<D>(a.dh, row0, lrow, col);
+        FZ_FOR_ACC { acc_st<D>(dho, rb, reg, acc_h[0][rb][reg]); }
+    }
+}
+#undef LOFF
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 4) * sizeof(float); }
+
+extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
+
+template <int D, bool FIRST>
+static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
+    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST> : (const void*)k_ggnn_step_fwd<D, FIRST>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
+    if (e != hipSuccess) return (int)e;
+    const double rows = (double)n_tiles * FZ_R;
+    const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
+    BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
+                      4.0 * rows * D * (bwd ? 13.0 : 6.0), st);
+    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D>
+static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
+    return a.first ? fz_launch2<D, true>(bwd, a, n_tiles, st) : fz_launch2<D, false>(bwd, a, n_tiles, st);
+}
+
+// One GGNN propagation step, forward (models/ggnn.py:215-263): m = message(h), h' = GRU([h, m]).
+// Weight layouts as bmp_msg_fwd / bmp_gru_fwd.  Saves m [N x d], rz [N x 2d], c [N x d].
+extern "C" int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
+                                 const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
+                                 const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+    StepArgs a; memset(&a, 0, sizeof(a));
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first;
+    a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
+    return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
+}
+
+// Backward-data of one step: dh (gradient w.r.t. the step input h) and gda [N x 7d] =
+// [G_0..G_3 | da_r | da_z | da_c] for bmp_ggnn_step_wgrad.  Wnat [d x 4d], A [3d x 2d], Uc [d x d].
+extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d,
+                                 int first, const int* csrT_ptr, const int* csrT_col, const float* csrT_val,
+                                 const float* Wnat, const float* A, const float* Uc, float* dh, float* gda, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+    StepArgs a; memset(&a, 0, sizeof(a));
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first;
+    a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
+    return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
+}
+
+extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
+    size_t s = bmp_wgrad_ws_floats(N, d, 7 * d);
+    size_t s2 = bmp_colsum_ws_floats(N, 7 * d);
+    return s > s2 ? s : s2;
+}
+
+// Weight gradients of one step (reduction over all N = n_tiles*128 rows):
+//   o1 [d x 7d]  = h^T . gda        cols [0,4d): dWT as [k][e*d + c];  cols [4d,7d): dAT rows 0..d-1
+//   o2 [d x 3d]  = m^T . da         = dAT rows d..2d-1
+//   dUcT [d x d] = (r*h)^T . da_c   (zeros when first)
+//   cs [7d]      = column sums of gda: [dbE as e*d + c | db]
+// accumulate != 0 adds into the outputs (weight tying: one set of buffers for all steps).
+extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
+                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
+                                   size_t ws_floats, hipStream_t st) {
+    BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
+    int rc;
+    WGArgs g1{h, nullptr, d, 0, gda, 7 * d, d, 7 * d, N, o1, 7 * d, accumulate};
+    if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
+    WGArgs g2{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, 3 * d, N, o2, 3 * d, accumulate};
+    if ((rc = bmp_launch_wgrad(g2, ws, st))) return rc;
+    if (!first) {
+        WGArgs g3{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
+        if ((rc = bmp_launch_wgrad(g3, ws, st))) return rc;
+    } else if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return bmp_launch_colsum(gda, 7 * d, N, 7 * d, cs, accumulate, ws, st);
+}

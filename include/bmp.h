@@ -71,6 +71,25 @@ int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float*
                 int first, const float* A, const float* Uc, float* dh, float* dm, float* dAT, float* dUcT, float* db,
                 float* ws, size_t ws_floats, bmp_stream_t stream);
 
+/* One whole GGNN propagation step, fused per 128-row tile -- GGNN.update models/ggnn.py:215-263
+ * (message + GRU in one kernel, the tile's atom states resident in LDS).  d must satisfy
+ * bmp_ggnn_step_supported(d) (64 or 128); other widths use bmp_msg_* + bmp_gru_*.
+ * Weight layouts as bmp_msg_fwd / bmp_gru_fwd.  fwd saves m [N x d], rz [N x 2d], c [N x d].
+ * bwd writes dh [N x d] and gda [N x 7d] = [G_0..G_3 (transposed-gathered dm per bond type) | da_r | da_z | da_c];
+ * wgrad reduces over the N rows: o1 [d x 7d] = h^T.gda (cols [0,4d): dWT as [k][e*d+c]; cols [4d,7d): dAT rows
+ * 0..d-1), o2 [d x 3d] = m^T.da (dAT rows d..2d-1), dUcT [d x d], cs [7d] = column sums (dbE | db). */
+int bmp_ggnn_step_supported(int d);
+int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
+                      const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
+                      const float* b, float* m, float* rz, float* c, float* hout, bmp_stream_t stream);
+int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
+                      const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
+                      const float* Uc, float* dh, float* gda, bmp_stream_t stream);
+size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
+int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first,
+                        float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats,
+                        bmp_stream_t stream);
+
 /* Gated-sum readout -- GGNN.readout models/ggnn.py:333-341 and GGNNReadout.__call__
  * models/readout/ggnn_readout.py:42-57.  g[mol] = sum_rows w * sigmoid(i(.)) * act_j(j(.)).
  * WT [(d+d0) x 2o] cols [i|j]; h0 may be NULL (d0 ignored).  Saves ij [N x 2o]. */
