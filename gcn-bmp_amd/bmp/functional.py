@@ -156,12 +156,28 @@ def step_supported(d: int) -> bool:
     return bool(_lib.lib().bmp_ggnn_step_supported(int(d)))
 
 
+def pack_k4(W: torch.Tensor) -> torch.Tensor:
+    """K-major [K x N] weight -> the fused kernels' B-operand layout [K/4][N][4]: a lane's four
+    consecutive k values of one output column are one 16-byte load, 64 lanes are 1 KiB contiguous."""
+    K, N = W.shape
+    return W.detach().reshape(K // 4, 4, N).permute(0, 2, 1).contiguous()
+
+
+def _cached(cache, key, make):
+    if cache is None:
+        return make()
+    if key not in cache:
+        cache[key] = make()
+    return cache[key]
+
+
 class GGNNStepFn(Function):
     """One whole propagation step (message + GRU) as ONE fused kernel per tile
-    (models/ggnn.py:215-263).  Same weight layouts as MsgFn / GRUFn."""
+    (models/ggnn.py:215-263).  Same weight layouts as MsgFn / GRUFn; ``cache`` (a dict that lives
+    for one encoder call) shares the packed weight copies between the steps of tied layers."""
 
     @staticmethod
-    def forward(ctx, h, WT, bE, AT, UcT, b, pb, first):
+    def forward(ctx, h, WT, bE, AT, UcT, b, pb, first, cache=None):
         L = _lib.lib()
         require_rows(h, "step: h")
         _check_pb(pb, h)
@@ -169,25 +185,30 @@ class GGNNStepFn(Function):
         if tuple(WT.shape) != (4 * d, d) or tuple(bE.shape) != (4, d) or tuple(AT.shape) != (2 * d, 3 * d) \
                 or tuple(UcT.shape) != (d, d) or tuple(b.shape) != (3 * d,):
             raise ValueError("step: weight shapes do not match h")
-        WT, bE, AT, UcT, b = WT.contiguous(), bE.contiguous(), AT.contiguous(), UcT.contiguous(), b.contiguous()
+        bE, b = bE.contiguous(), b.contiguous()
+        WTp = _cached(cache, ("f", WT.data_ptr()), lambda: pack_k4(WT))
+        ATp = _cached(cache, ("f", AT.data_ptr()), lambda: pack_k4(AT))
+        UcTp = _cached(cache, ("f", UcT.data_ptr()), lambda: pack_k4(UcT))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
         check(L.bmp_ggnn_step_fwd(ptr(h), pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
-                                  ptr(WT), ptr(bE), ptr(AT), ptr(UcT), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout),
+                                  ptr(WTp), ptr(bE), ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout),
                                   stream()), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, WT, AT, UcT, m, rz, c)
-        ctx.pb, ctx.first = pb, int(first)
+        ctx.pb, ctx.first, ctx.cache = pb, int(first), cache
         return hout
 
     @staticmethod
     def backward(ctx, dhout):
         L = _lib.lib()
         h, WT, AT, UcT, m, rz, c = ctx.saved_tensors
-        pb, first = ctx.pb, ctx.first
+        pb, first, cache = ctx.pb, ctx.first, ctx.cache
         N, d = h.shape
         dev = h.device
         dhout = dhout.contiguous()
-        Wnat, A, Uc = WT.t().contiguous(), AT.t().contiguous(), UcT.t().contiguous()
+        Wnat = _cached(cache, ("b", WT.data_ptr()), lambda: pack_k4(WT.t()))
+        A = _cached(cache, ("b", AT.data_ptr()), lambda: pack_k4(AT.t()))
+        Uc = _cached(cache, ("b", UcT.data_ptr()), lambda: pack_k4(UcT.t()))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         dh, gda = f(N, d), f(N, 7 * d)
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
@@ -201,7 +222,7 @@ class GGNNStepFn(Function):
         dWT = o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)      # [k][e*d+c] -> [e*d+k][c]
         dbE = cs[:4 * d].reshape(4, d)
         dAT = torch.cat((o1[:, 4 * d:], o2), dim=0)
-        return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None
+        return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None, None
 
 
 class ReadoutFn(Function):

@@ -167,9 +167,12 @@ class GGNN(nn.Module):
         later = None
         fused = self.fused and Fn.step_supported(self.hidden_dim)
         g_list = []
+        msgw, cache = {}, {}          # per-call: kernel-layout weights of each layer, packed copies
         for step in range(self.n_layers):                               # :616
             li = 0 if self.weight_tying else step                       # :220
-            WT, bE = message_kernel_weights(self.message_layers[li])
+            if li not in msgw:
+                msgw[li] = message_kernel_weights(self.message_layers[li])
+            WT, bE = msgw[li]
             if step == 0:
                 AT, UcT, b = self.update_layer.kernel_weights(first=True)
             else:
@@ -177,7 +180,7 @@ class GGNN(nn.Module):
                     later = self.update_layer.kernel_weights(first=False)
                 AT, UcT, b = later
             if fused:       # message + GRU in one kernel per tile, atom states resident in LDS
-                h = Fn.GGNNStepFn.apply(h, WT, bE, AT, UcT, b, pb, step == 0)
+                h = Fn.GGNNStepFn.apply(h, WT, bE, AT, UcT, b, pb, step == 0, cache)
             else:
                 m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
                 h = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, step == 0)    # :254-262, state reset at :599

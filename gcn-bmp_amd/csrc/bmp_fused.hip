@@ -43,18 +43,14 @@ struct StepArgs {
 template <int NB, int RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
                                          const int (&ldw)[NB], int K) {
-    float bc[NB][4], bn[NB][4];
+    f32x4 bc[NB], bn[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bc[nb][t] = Bp[nb][(size_t)t * ldw[nb]];
+    for (int nb = 0; nb < NB; ++nb) bc[nb] = *(const f32x4*)(Bp[nb]);
 #pragma unroll 2
     for (int kk = 0; kk < K; kk += 8) {
         if (kk + 8 < K) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) bn[nb][t] = Bp[nb][(size_t)(kk + 8 + t) * ldw[nb]];
+            for (int nb = 0; nb < NB; ++nb) bn[nb] = *(const f32x4*)(Bp[nb] + (size_t)(kk + 8) * ldw[nb]);
         }
         f32x4 av[RB];
 #pragma unroll
@@ -66,9 +62,7 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(av[rb][t], bc[nb][t], acc[nb][rb]);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bc[nb][t] = bn[nb][t];
+        for (int nb = 0; nb < NB; ++nb) bc[nb] = bn[nb];
     }
 }
 
@@ -178,7 +172,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
         const int any = __syncthreads_or(mine ? 1 : 0);
         if (any) {
-            const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + col};
+            const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
             const int ldw[1] = {D};
             tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D);
         }
@@ -205,21 +199,21 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     zero_acc(acc_g[0]); zero_acc(acc_g[1]); zero_acc(acc_g[2]);
     {
         const int ldw3[3] = {3 * D, 3 * D, 3 * D};
-        const float* base_h = a.AT + (size_t)(4 * hi) * 3 * D + col;
-        const float* base_m = a.AT + (size_t)(D + 4 * hi) * 3 * D + col;
+        const float* base_h = a.AT + (size_t)(4 * hi) * 3 * D + 4 * col;
+        const float* base_m = a.AT + (size_t)(D + 4 * hi) * 3 * D + 4 * col;
         if (FIRST) {      // first call after reset: z and c only, no state terms
             f32x16 g2[2][RB];
             zero_acc(g2[0]); zero_acc(g2[1]);
             const int ldw2[2] = {3 * D, 3 * D};
-            const float* const Bh[2] = {base_h + D, base_h + 2 * D};
-            const float* const Bm[2] = {base_m + D, base_m + 2 * D};
+            const float* const Bh[2] = {base_h + 4 * D, base_h + 8 * D};
+            const float* const Bm[2] = {base_m + 4 * D, base_m + 8 * D};
             tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D);
             tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) { acc_g[1][rb] = g2[0][rb]; acc_g[2][rb] = g2[1][rb]; }
         } else {
-            const float* const Bh[3] = {base_h, base_h + D, base_h + 2 * D};
-            const float* const Bm[3] = {base_m, base_m + D, base_m + 2 * D};
+            const float* const Bh[3] = {base_h, base_h + 4 * D, base_h + 8 * D};
+            const float* const Bm[3] = {base_m, base_m + 4 * D, base_m + 8 * D};
             tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D);
             tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D);
         }
@@ -245,7 +239,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         f32x16 gc[1][RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
-        const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + col};
+        const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
         const int ldu[1] = {D};
         tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D);
 #pragma unroll
@@ -309,19 +303,19 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     }
     __syncthreads();
 
-    const float* const Ac_h = a.A + (size_t)(2 * D + 4 * hi) * 2 * D + col;
-    const float* const Az_h = a.A + (size_t)(D + 4 * hi) * 2 * D + col;
-    const float* const Ar_h = a.A + (size_t)(4 * hi) * 2 * D + col;
+    const float* const Ac_h = a.A + (size_t)(2 * D + 4 * hi) * 2 * D + 4 * col;
+    const float* const Az_h = a.A + (size_t)(D + 4 * hi) * 2 * D + 4 * col;
+    const float* const Ar_h = a.A + (size_t)(4 * hi) * 2 * D + 4 * col;
     const int ld2[2] = {2 * D, 2 * D};
     {   // [dh | dm] += da_c . A_c
-        const float* const Bc[2] = {Ac_h, Ac_h + D};
+        const float* const Bc[2] = {Ac_h, Ac_h + 4 * D};
         tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D);
     }
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
         zero_acc(acc_d[0]);
         {
-            const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + col};
+            const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
             tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D);
         }
@@ -338,7 +332,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         }
         __syncthreads();
         {   // X = da_r
-            const float* const Br[2] = {Ar_h, Ar_h + D};
+            const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
             tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D);
         }
     }
@@ -356,7 +350,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     }
     __syncthreads();
     {
-        const float* const Bz[2] = {Az_h, Az_h + D};
+        const float* const Bz[2] = {Az_h, Az_h + 4 * D};
         tile_mma<2, RB>(acc_x, Xw, LD, Bz, ld2, D);
     }
     __syncthreads();                         // all waves done with X
@@ -380,7 +374,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         }
         const int any = __syncthreads_or(mine ? 1 : 0);
         if (any) {
-            const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + e * D + col};
+            const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
             const int ldw[1] = {4 * D};
             tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D);
         }

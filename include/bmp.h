@@ -74,7 +74,10 @@ int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float*
 /* One whole GGNN propagation step, fused per 128-row tile -- GGNN.update models/ggnn.py:215-263
  * (message + GRU in one kernel, the tile's atom states resident in LDS).  d must satisfy
  * bmp_ggnn_step_supported(d) (64 or 128); other widths use bmp_msg_* + bmp_gru_*.
- * Weight layouts as bmp_msg_fwd / bmp_gru_fwd.  fwd saves m [N x d], rz [N x 2d], c [N x d].
+ * Weights have the shapes of bmp_msg_fwd / bmp_gru_fwd but are "K4-packed": a K-major [K x N] matrix
+ * is stored as [K/4][N][4] (element (k, n) at ((k/4)*N + n)*4 + k%4), so one lane's four consecutive
+ * k values of a column are a single 16-byte load (WT, AT, UcT for fwd; Wnat [d x 4d], A [3d x 2d],
+ * Uc [d x d] for bwd).  fwd saves m [N x d], rz [N x 2d], c [N x d].
  * bwd writes dh [N x d] and gda [N x 7d] = [G_0..G_3 (transposed-gathered dm per bond type) | da_r | da_z | da_c];
  * wgrad reduces over the N rows: o1 [d x 7d] = h^T.gda (cols [0,4d): dWT as [k][e*d+c]; cols [4d,7d): dAT rows
  * 0..d-1), o2 [d x 3d] = m^T.da (dAT rows d..2d-1), dUcT [d x d], cs [7d] = column sums (dbE | db). */
