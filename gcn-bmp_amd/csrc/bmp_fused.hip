@@ -77,6 +77,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 // Tile-local neighbour gather for one bond type: dst[row, :] = sum over CSR entries of `row` with type e of
 // val * src_tile[col_local, :].  4 threads per row, D/4 columns each.  Returns (per thread) whether it saw a
 // matching entry; *wsum gets the row's weighted degree for that type.
+// ptr is indexed by the tile-local row; col/val by the entry index ptr yields (either the kernel's global CSR
+// arrays, or the copy of the tile's entries staged in LDS -- see stage_csr).
 template <int D>
 __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_tile, int LD, const int* ptr, const int* col,
                                             const float* val, int row0, int e, float* wsum) {
@@ -87,7 +89,7 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
     for (int f = 0; f < F; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float wd = 0.f;
     bool any = false;
-    const int e0 = ptr[row0 + row], e1 = ptr[row0 + row + 1];
+    const int e0 = ptr[row], e1 = ptr[row + 1];
     for (int ed = e0; ed < e1; ++ed) {
         const int cv = col[ed];
         if ((cv & 3) == e) {
@@ -105,6 +107,21 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
     *wsum = wd;
     return any;
 }
+
+// The tile's CSR entries -> LDS (the gather loops are chains of dependent loads: from L2 they cost several
+// microseconds per bond-type pass).  Returns false (and stages nothing) if the tile has more than FZ_ECAP entries.
+#define FZ_ECAP 1024
+__device__ __forceinline__ bool stage_csr(const int* ptr, const int* col, const float* val, int row0, int* rptr, int* ecol,
+                                          float* evalv) {
+    const int ebase = ptr[row0];
+    const int ne = ptr[row0 + FZ_R] - ebase;
+    if (ne > FZ_ECAP) return false;
+    for (int i = threadIdx.x; i <= FZ_R; i += 512) rptr[i] = ptr[row0 + i] - ebase;
+    for (int i = threadIdx.x; i < ne; i += 512) { ecol[i] = col[ebase + i]; evalv[i] = val[ebase + i]; }
+    return true;
+}
+#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp) \
+                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp))
 
 // Accumulator-layout access to a row-major [rows x LDC] f32 array through a buffer resource: all 16*RB
 // positions of a wave share ONE 32-bit voffset VGPR (the lane's (row, col) byte offset); the per-register
@@ -142,6 +159,9 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     float* Hs = lds;                         // [128 x LD]  h tile (whole step)
     float* As = lds + FZ_R * LD;             // [128 x LD]  AGG_e -> M -> r*h
     float* wds = As + FZ_R * LD;             // [128 x 4]   weighted degree per bond type
+    int* rptr = (int*)(wds + FZ_R * 4);      // [132]       tile-relative CSR row pointers
+    int* ecol = rptr + 132;                  // [FZ_ECAP]
+    float* evalv = (float*)(ecol + FZ_ECAP); // [FZ_ECAP]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wc = w % NCB, wr = w / NCB;
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
         *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
     }
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);
     __syncthreads();
 
     // ---- message: m = sum_e AGG_e . W_e + wdeg_e * b_e   (models/ggnn.py:223-242) ----
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     zero_acc(acc_m[0]);
     for (int e = 0; e < 4; ++e) {
         float wd;
-        const bool mine = tile_gather<D>(Hs, As, LD, a.ptr, a.col, a.val, row0, e, &wd);
+        const bool mine = FZ_GATHER(Hs, As, e, &wd);
         if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
         const int any = __syncthreads_or(mine ? 1 : 0);
         if (any) {
@@ -270,6 +291,9 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Xs = lds;                         // [128 x LD]  da_c -> da_r -> da_z -> dm
     float* Ys = lds + FZ_R * LD;             // [128 x LD]  G_e (transposed gather of dm)
+    int* rptr = (int*)(Ys + FZ_R * LD + FZ_R * 4);
+    int* ecol = rptr + 132;
+    float* evalv = (float*)(ecol + FZ_ECAP);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wc = w % NCB, wr = w / NCB;
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     float* Xl = Xs + lrow * LD + col;
     constexpr bool first = FIRST;
 
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);     // visible after the first barrier
     const AccBuf gi = acc_buf<D>(a.dhout, row0, lrow, col);
     const AccBuf ci = acc_buf<D>(a.c, row0, lrow, col);
     const AccBuf hin = acc_buf<D>(a.h, row0, lrow, col);
@@ -364,7 +389,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     for (int rb = 0; rb < RB; ++rb) acc_h[0][rb] = acc_x[0][rb];
     for (int e = 0; e < 4; ++e) {
         float wd;
-        const bool mine = tile_gather<D>(Xs, Ys, LD, a.ptr, a.col, a.val, row0, e, &wd);
+        const bool mine = FZ_GATHER(Xs, Ys, e, &wd);
         {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + row * LD + q * (D / 4);
@@ -390,7 +415,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 4) * sizeof(float); }
+static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 4 + 132 + 2 * FZ_ECAP) * sizeof(float); }
 
 extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 
