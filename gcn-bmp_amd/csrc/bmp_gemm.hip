@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void k_wgrad(WGKArgs a) {
 
 // out[i, j] (=|+=) sum_s slab[s][i][j]
 // 64 elements x 4 slab lanes per workgroup; fixed summation order (bitwise reproducible).
+// Slabs are [S][K][Nn]; row `cs_row` (if >= 0) holds column sums and goes to cs_out instead of out.
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab, int S, int K, int Nn, float* out,
-                                                      int ldo, int accumulate) {
+                                                      int ldo, int accumulate, int cs_row, float* cs_out) {
     __shared__ float red[4][64];
     const size_t total = (size_t)K * Nn;
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -260,10 +261,116 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
         if (g == 0 && idx < total) {
             v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
             const int i = (int)(idx / Nn), j = (int)(idx % Nn);
-            float* o = out + (size_t)i * ldo + j;
+            float* o = (i == cs_row) ? (cs_out + j) : (out + (size_t)i * ldo + j);
             *o = accumulate ? (*o + v) : v;
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged weight-gradient GEMM for the big shapes: one 128x128 output tile per workgroup, rows
+// streamed in 32-row stages through a double-buffered LDS image (global loads of stage s+1 are in
+// flight while stage s feeds the MFMAs), operands shared by the four waves.  Optionally also
+// emits the column sums of dY (bias gradients) as slab row K: dY is being read anyway.
+// ---------------------------------------------------------------------------------------------
+#define WG_LD 132
+template <bool HAS_X2>
+__global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
+    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
+    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int i_tile = blockIdx.x * 128, j_tile = blockIdx.y * 128;
+    const int s = blockIdx.z;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) >> 5;
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int colx = i_tile + 4 * c4, coly = j_tile + 4 * c4;
+    const bool okx = colx < a.K, oky = coly < a.Nn;
+    const bool do_cs = want_cs && blockIdx.x == 0;
+    const int Krows = a.K + (want_cs ? 1 : 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 xr[4], yr[4];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define WG_LOAD(st)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+        const size_t row = (size_t)(r_begin + (st) * 32 + rr + 8 * i);                               \
+        xr[i] = okx ? *(const f32x4*)(a.X + row * a.ldx + colx) : zero4;                              \
+        if (HAS_X2 && okx) xr[i] *= *(const f32x4*)(a.X2 + row * a.ldx2 + colx);                     \
+        yr[i] = oky ? *(const f32x4*)(a.dY + row * a.ldy + coly) : zero4;                             \
+    }
+#define WG_STORE(buf)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+        *(f32x4*)(&XS[buf][rr + 8 * i][4 * c4]) = xr[i];                                             \
+        *(f32x4*)(&YS[buf][rr + 8 * i][4 * c4]) = yr[i];                                             \
+        csum += yr[i];                                                                               \
+    }
+
+    if (nst > 0) {
+        WG_LOAD(0)
+        WG_STORE(0)
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) { WG_LOAD(st + 1) }
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            float av[2][4], bv[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) av[m][t] = XS[buf][k0 + 4 * hi + t][wm * 64 + m * 32 + l31];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) bv[n][t] = YS[buf][k0 + 4 * hi + t][wn * 64 + n * 32 + l31];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[m][t], bv[n][t], acc[m][n]);
+        }
+        if (st + 1 < nst) { WG_STORE(buf ^ 1) }
+        __syncthreads();
+    }
+#undef WG_LOAD
+#undef WG_STORE
+
+    float* slab = a.slab + (size_t)s * Krows * a.Nn;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = i_tile + wm * 64 + m * 32 + bmp_acc_row(reg, lane);
+                if (i < a.K && j < a.Nn) slab[(size_t)i * a.Nn + j] = acc[m][n][reg];
+            }
+        }
+    if (do_cs) {        // column sums of this split's dY rows: reduce the 8 row groups through LDS
+        f32x4* red = (f32x4*)&XS[0][0][0];
+        red[rr * 32 + c4] = csum;
+        __syncthreads();
+        if (rr == 0 && oky) {
+            f32x4 t = red[c4];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += red[g * 32 + c4];
+            *(f32x4*)(slab + (size_t)a.K * a.Nn + coly) = t;
+        }
     }
 }
 
@@ -281,14 +388,59 @@ static void wgrad_plan(int N, int K, int Nn, int& mb, int& nb, int& S, int& rps)
     S = (N + rps - 1) / rps;
 }
 
+static bool wgrad_use_lds(const WGArgs& a) {
+    return a.K >= 64 && a.Nn >= 64 && (a.K & 3) == 0 && (a.Nn & 3) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 &&
+           (a.N & 31) == 0 && ((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.dY & 15) == 0 &&
+           (!a.X2 || ((a.ldx2 & 3) == 0 && ((uintptr_t)a.X2 & 15) == 0));
+}
+
+static void wgrad_lds_plan(int N, int K, int Nn, int& S, int& rps) {
+    const int tiles = ((K + 127) / 128) * ((Nn + 127) / 128);
+    int want = (512 + tiles - 1) / tiles;             // ~2 workgroups per CU in total
+    int max_s = N / 256;                              // at least 256 rows (8 stages) per split
+    if (max_s < 1) max_s = 1;
+    S = want < max_s ? want : max_s;
+    if (S < 1) S = 1;
+    rps = (N + S - 1) / S;
+    rps = (rps + 31) & ~31;
+    S = (N + rps - 1) / rps;
+}
+
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn) {
     int mb, nb, S, rps;
     wgrad_plan(N, K, Nn, mb, nb, S, rps);
-    return (size_t)S * K * Nn;
+    size_t a = (size_t)S * K * Nn;
+    int S2, rps2;
+    wgrad_lds_plan(N, K, Nn, S2, rps2);
+    size_t b = (size_t)S2 * (K + 1) * Nn;
+    size_t c = bmp_colsum_ws_floats(N, Nn);
+    a = a > b ? a : b;
+    return a > c ? a : c;
 }
 
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     BMP_REQUIRE(a.N > 0 && (a.N & 7) == 0 && a.K > 0 && a.Nn > 0 && ws != nullptr);
+    if (wgrad_use_lds(a)) {
+        int S, rps;
+        wgrad_lds_plan(a.N, a.K, a.Nn, S, rps);
+        const int want_cs = a.cs != nullptr;
+        WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws};
+        dim3 grid((a.K + 127) / 128, (a.Nn + 127) / 128, S);
+        {
+            BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st);
+            if (a.X2) hipLaunchKernelGGL((k_wgrad_lds<true>), grid, dim3(256), 0, st, k, want_cs);
+            else hipLaunchKernelGGL((k_wgrad_lds<false>), grid, dim3(256), 0, st, k, want_cs);
+        }
+        BMP_LAUNCH_CHECK();
+        const int Krows = a.K + want_cs;
+        const size_t total = (size_t)Krows * a.Nn;
+        int blocks = (int)((total + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, ws, S, Krows, a.Nn, a.out, a.ldo, a.accumulate,
+                           want_cs ? a.K : -1, a.cs);
+        BMP_LAUNCH_CHECK();
+        return 0;
+    }
     int mb, nb, S, rps;
     wgrad_plan(a.N, a.K, a.Nn, mb, nb, S, rps);
     WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws};
@@ -304,8 +456,10 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     const size_t total = (size_t)a.K * a.Nn;
     int blocks = (int)((total + 63) / 64);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, ws, S, a.K, a.Nn, a.out, a.ldo, a.accumulate);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, ws, S, a.K, a.Nn, a.out, a.ldo, a.accumulate, -1,
+                       (float*)nullptr);
     BMP_LAUNCH_CHECK();
+    if (a.cs) return bmp_launch_colsum(a.dY, a.ldy, a.N, a.Nn, a.cs, a.accumulate, ws, st);
     return 0;
 }
 
@@ -347,7 +501,8 @@ int bmp_launch_colsum(const float* dY, int ldy, int N, int Nn, float* out, int a
     colsum_plan(N, S, rps);
     hipLaunchKernelGGL(k_colsum, dim3((Nn + 63) / 64, S), dim3(256), 0, st, dY, ldy, N, Nn, rps, ws);
     BMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((Nn + 63) / 64), dim3(256), 0, st, ws, S, 1, Nn, out, Nn, accumulate);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((Nn + 63) / 64), dim3(256), 0, st, ws, S, 1, Nn, out, Nn, accumulate, -1,
+                       (float*)nullptr);
     BMP_LAUNCH_CHECK();
     return 0;
 }
