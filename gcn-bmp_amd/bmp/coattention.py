@@ -32,6 +32,17 @@ class Bilinear(nn.Module):
         self.b = nn.Parameter(torch.zeros(out))
 
 
+def _size_classes(nr1: np.ndarray, nr2: np.ndarray, device):
+    """Pairs grouped by size class ceil(max(n1, n2) / 32): the pair kernels are launched once per
+    class with LDS sized for it (most drug pairs are <= 32 or <= 64 atoms)."""
+    cls = (np.maximum(nr1, nr2) + 31) // 32 - 1
+    order = np.argsort(cls, kind="stable").astype(np.int32)
+    counts = np.bincount(cls, minlength=4)
+    if len(counts) > 4:
+        raise ValueError("a molecule has more than 128 rows")
+    return torch.from_numpy(order).to(device), [int(c) for c in counts]
+
+
 def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
     """Row tensors and per-pair row ranges of the two sides.
 
@@ -53,8 +64,8 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
                 B=B, T1=T1, T2=pb1.side_tiles[2] - T1,
                 r1=pb1.mol_row0[:B].contiguous(), n1=pb1.mol_nrows[:B].contiguous(),
                 r2=(pb1.mol_row0[B:] - T1 * R).contiguous(), n2=pb1.mol_nrows[B:].contiguous(),
-                coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]),
-                maxn=int(nr.max()))
+                coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
+            pb1._cache[key]["order"], pb1._cache[key]["counts"] = _size_classes(nr[:B], nr[B:], pb1.device)
         m = pb1._cache[key]
         N1 = m["T1"] * R
         X1, X2 = at1.rows[:N1], at1.rows[N1:]
@@ -67,8 +78,8 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
     nr1, nr2 = pb1.mol_nrows_host, pb2.mol_nrows_host
     coff = np.concatenate(([0], np.cumsum(nr1 * nr2)))
     m = dict(B=pb1.n_mols, T1=pb1.n_tiles, T2=pb2.n_tiles, r1=pb1.mol_row0, n1=pb1.mol_nrows, r2=pb2.mol_row0,
-             n2=pb2.mol_nrows, coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]),
-             maxn=int(max(nr1.max(), nr2.max())))
+             n2=pb2.mol_nrows, coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
+    m["order"], m["counts"] = _size_classes(nr1, nr2, pb1.device)
     return at1.rows, at2.rows, pb1.row_w, pb2.row_w, m, False
 
 
@@ -92,8 +103,8 @@ class NieCoattnFn(Function):
         al1, al2 = torch.zeros(N1, device=dev), torch.zeros(N2, device=dev)
         out1, out2 = f(B, o), f(B, o)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
-                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, meta["maxn"],
-                                   ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
+                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order"]),
+                                   *meta["counts"], ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
                                    ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(out1),
                                    ptr(out2), stream()), "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
@@ -118,7 +129,8 @@ class NieCoattnFn(Function):
         ws = _ws(nws, dev)
         check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1),
                                    ptr(meta["r1"]), ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]),
-                                   ptr(meta["coff"]), B, meta["maxn"], ptr(Wb), ptr(ZW1), ptr(ZW2), ptr(wa1), ptr(wa2),
+                                   ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], ptr(Wb), ptr(ZW1), ptr(ZW2), ptr(wa1),
+                                   ptr(wa2),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
                                    stream()), "bmp_coattn_nie_bwd")

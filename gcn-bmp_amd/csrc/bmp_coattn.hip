@@ -23,6 +23,8 @@ struct CoArgs {
     const float* w1; const float* w2;
     const int* r1; const int* n1; const int* r2; const int* n2;   // per pair row range
     const long long* coff;                     // per pair offset into Cbuf
+    const int* order; int order_off;           // pair processed by block i = order[order_off + i] (size-class launch)
+    int np;                                    // class size: every pair of this launch has n1, n2 <= np (multiple of 32)
     const float* wa1; const float* wa2; const float* cbias;
     int d, o, H, act, ldc;
     float* Cbuf;                               // ragged: pair b holds C (n2 x n1), row-major
@@ -47,43 +49,41 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// LDS carve-up shared by forward and backward
+// LDS carve-up shared by forward and backward; every extent scales with the launch's size class np
 struct CoLds {
-    float* Cs;      // [n2p x ldc]
-    float* dSs;     // [n2p x ldc]   (backward only)
-    float* P1s;     // [MAXN x H]
+    float* Cs;      // [np x ldc]
+    float* dSs;     // [np x ldc]   (backward only)
+    float* P1s;     // [np x H]
     float* P2s;
-    float* dH1s;    // [MAXN x H]    (backward only)
+    float* dH1s;    // [np x H]     (backward only)
     float* dH2s;
     float* w1s; float* w2s; float* v2s;
-    float* cst;     // cmax[MAXN] | invD2[MAXN] | rmax[MAXN] | invD1[MAXN]
+    float* cmax; float* invD2; float* rmax; float* invD1;
     float* s1; float* s2;            // scores / alphas
-    float* dots;    // [2*MAXN]
+    float* dots1; float* dots2;
 };
 
-__device__ __forceinline__ CoLds co_carve(float* base, int n2p, int ldc, int H, bool bwd) {
+__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd) {
     CoLds L;
     float* p = base;
-    L.Cs = p; p += (size_t)n2p * ldc;
-    L.dSs = p; if (bwd) p += (size_t)n2p * ldc;
-    L.P1s = p; p += CO_MAXN * H;
-    L.P2s = p; p += CO_MAXN * H;
-    L.dH1s = p; if (bwd) p += CO_MAXN * H;
-    L.dH2s = p; if (bwd) p += CO_MAXN * H;
-    L.w1s = p; p += CO_MAXN;
-    L.w2s = p; p += CO_MAXN;
-    L.v2s = p; p += CO_MAXN;
-    L.cst = p; p += 4 * CO_MAXN;
-    L.s1 = p; p += CO_MAXN;
-    L.s2 = p; p += CO_MAXN;
-    L.dots = p; p += 2 * CO_MAXN;
+    L.Cs = p; p += (size_t)np * ldc;
+    L.dSs = p; if (bwd) p += (size_t)np * ldc;
+    L.P1s = p; p += np * H;
+    L.P2s = p; p += np * H;
+    L.dH1s = p; if (bwd) p += np * H;
+    L.dH2s = p; if (bwd) p += np * H;
+    L.w1s = p; p += np;
+    L.w2s = p; p += np;
+    L.v2s = p; p += np;
+    L.cmax = p; p += np; L.invD2 = p; p += np; L.rmax = p; p += np; L.invD1 = p; p += np;
+    L.s1 = p; p += np;
+    L.s2 = p; p += np;
+    L.dots1 = p; p += np; L.dots2 = p; p += np;
     return L;
 }
 
-static size_t co_lds_floats(int n2p, int ldc, int H, bool bwd) {
-    size_t f = (size_t)n2p * ldc * (bwd ? 2 : 1) + (size_t)CO_MAXN * H * (bwd ? 4 : 2) + 3 * CO_MAXN + 4 * CO_MAXN +
-               2 * CO_MAXN + 2 * CO_MAXN;
-    return f;
+static size_t co_lds_floats(int np, int ldc, int H, bool bwd) {
+    return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 4 : 2) + 11 * (size_t)np + 8;
 }
 
 // column / row softmax statistics of C with multiplicities:
@@ -98,7 +98,7 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
             for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
             float s = 0.f;
             for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) s += L.w2s[i] * expf(L.Cs[i * ldc + j] - mx);
-            L.cst[j] = mx; L.cst[CO_MAXN + j] = 1.f / s;
+            L.cmax[j] = mx; L.invD2[j] = 1.f / s;
         }
     } else {
         const int i = tid - CO_MAXN;
@@ -107,7 +107,7 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
             for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
             float s = 0.f;
             for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) s += L.w1s[j] * expf(L.Cs[i * ldc + j] - mx);
-            L.cst[2 * CO_MAXN + i] = mx; L.cst[3 * CO_MAXN + i] = 1.f / s;
+            L.rmax[i] = mx; L.invD1[i] = 1.f / s;
         }
     }
 }
@@ -115,21 +115,21 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
 // L2[i,j] (softmax over i) and L1[j,i] (softmax over j); zero-weight rows get weight 0 in every sum,
 // so their (possibly huge) exponent is never used.
 __device__ __forceinline__ float co_L2(const CoLds& L, int i, int j, int ldc) {
-    return L.w2s[i] > 0.f ? expf(L.Cs[i * ldc + j] - L.cst[j]) * L.cst[CO_MAXN + j] : 0.f;
+    return L.w2s[i] > 0.f ? expf(L.Cs[i * ldc + j] - L.cmax[j]) * L.invD2[j] : 0.f;
 }
 __device__ __forceinline__ float co_L1(const CoLds& L, int i, int j, int ldc) {
-    return L.w1s[j] > 0.f ? expf(L.Cs[i * ldc + j] - L.cst[2 * CO_MAXN + i]) * L.cst[3 * CO_MAXN + i] : 0.f;
+    return L.w1s[j] > 0.f ? expf(L.Cs[i * ldc + j] - L.rmax[i]) * L.invD1[i] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    const int b = blockIdx.x;
+    const int b = a.order[a.order_off + blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
     const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
-    const CoLds L = co_carve(lds_raw, nb2 * 32, ldc, H, false);
+    const CoLds L = co_carve(lds_raw, a.np, ldc, H, false);
     const float cb = a.cbias[0];
 
     for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
@@ -257,14 +257,14 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
 
 __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    const int b = blockIdx.x;
+    const int b = a.order[a.order_off + blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
     const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const int n1p = nb1 * 32, n2p = nb2 * 32;
-    const CoLds L = co_carve(lds_raw, ldc - 1, ldc, H, true);
+    const CoLds L = co_carve(lds_raw, a.np, ldc, H, true);
 
     // ---- load the pair's saved state ----
     for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
             dZ[c] = wa * g;
         }
         dot = wave_sum(dot);
-        if (lane == 0) L.dots[side * CO_MAXN + k] = dot;
+        if (lane == 0) (side == 0 ? L.dots1 : L.dots2)[k] = dot;
     }
     __syncthreads();
 
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     if (wave < 2) {
         const float* al = wave == 0 ? L.s1 : L.s2;
         const float* ww = wave == 0 ? L.w1s : L.w2s;
-        float* dt = L.dots + wave * CO_MAXN;
+        float* dt = wave == 0 ? L.dots1 : L.dots2;
         const int n = wave == 0 ? n1 : n2;
         float tsum = 0.f;
         for (int k = lane; k < n; k += 64) tsum += al[k] * ww[k] * dt[k];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         const int side = row < n1 ? 0 : 1;
         const int k = side == 0 ? row : row - n1;
         const float hv = side == 0 ? a.H1[(size_t)(r1 + k) * H + h] : a.H2[(size_t)(r2 + k) * H + h];
-        const float ds = L.dots[side * CO_MAXN + k];
+        const float ds = (side == 0 ? L.dots1 : L.dots2)[k];
         const float wa = side == 0 ? a.wa1[h] : a.wa2[h];
         (side == 0 ? L.dH1s : L.dH2s)[k * H + h] = ds * wa * (1.f - hv * hv);
     }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         float acc = 0.f;
         for (int k = 0; k < n; ++k) {
             const float hv = side == 0 ? a.H1[(size_t)(r1 + k) * H + h] : a.H2[(size_t)(r2 + k) * H + h];
-            acc += L.dots[side * CO_MAXN + k] * hv;
+            acc += (side == 0 ? L.dots1 : L.dots2)[k] * hv;
         }
         a.dpart[(size_t)b * (2 * H + 1) + side * H + h] = acc;
     }
@@ -413,10 +413,10 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
             a.dZ2[(size_t)(r2 + i) * ZC + o + H] = dv2;
         }
         const float tot = wave_sum(dv2);
-        if (lane == 0) L.dots[wave - 2] = tot;
+        if (lane == 0) L.dots1[wave - 2] = tot;
     }
     __syncthreads();
-    if (tid == 0) a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = L.dots[0] + L.dots[1];
+    if (tid == 0) a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = L.dots1[0] + L.dots1[1];
 
     // ---- energy backward on the matrix cores: dQ2 = dS . X1 ; dX1 = dS^T . Q2 ----
     const int ncb = (d + 31) >> 5;
@@ -469,12 +469,13 @@ extern "C" int bmp_coattn_zcols(int o, int H) { return (o + H + 1 + 7) & ~7; }
 // pass WbT[q*d + p] = W[p][q].  ZW1T/ZW2T [d x ZC] K-major columns [Wj^T | Wl_k^T | V_k | 0]; zb [ZC] = [bj | 0].
 extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act,
                                   const float* w1, const int* r1, const int* n1, const float* w2, const int* r2,
-                                  const int* n2, const long long* coff, int B, int maxn, const float* WbT,
+                                  const int* n2, const long long* coff, int B, const int* order, int n32, int n64, int n96,
+                                  int n128, const float* WbT,
                                   const float* ZW1T, const float* ZW2T, const float* zb, const float* wa1,
                                   const float* wa2, const float* cbias, float* Q2, float* Z1, float* Z2, float* Cbuf,
                                   float* H1, float* H2, float* al1, float* al2, float* out1, float* out2, hipStream_t st) {
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
-    BMP_REQUIRE(maxn > 0 && maxn <= CO_MAXN);
+    BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && n32 + n64 + n96 + n128 == B);
     const int ZC = bmp_coattn_zcols(o, H);
     int rc;
     {
@@ -489,18 +490,25 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         g.nsrc = 1; g.Nout = ZC; g.Y = s == 0 ? Z1 : Z2; g.ldy = ZC; g.bias = zb;
         if ((rc = bmp_launch_rowgemm(g, s == 0 ? n_tiles1 : n_tiles2, BMP_EPI_GENERIC, st))) return rc;
     }
-    const int np = (maxn + 31) & ~31;
-    const int ldc = np + 1;
-    const size_t lds = co_lds_floats(np, ldc, H, false) * sizeof(float);
-    BMP_REQUIRE(lds <= 160 * 1024);
     if ((rc = co_set_lds((const void*)k_coattn_fwd, 160 * 1024))) return rc;
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
-    a.d = d; a.o = o; a.H = H; a.act = act; a.ldc = ldc;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.order = order;
     a.Cbuf = Cbuf; a.H1 = H1; a.H2 = H2; a.al1 = al1; a.al2 = al2; a.out1 = out1; a.out2 = out2;
-    hipLaunchKernelGGL(k_coattn_fwd, dim3(B), dim3(256), lds, st, a);
-    BMP_LAUNCH_CHECK();
+    // one launch per size class: LDS (and so the workgroups per CU) follows the pairs' actual sizes
+    const int cnt[4] = {n32, n64, n96, n128};
+    int off = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (cnt[c] == 0) continue;
+        a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
+        const size_t lds = co_lds_floats(a.np, a.ldc, H, false) * sizeof(float);
+        BMP_REQUIRE(lds <= 160 * 1024);
+        BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
+        hipLaunchKernelGGL(k_coattn_fwd, dim3(cnt[c]), dim3(256), lds, st, a);
+        BMP_LAUNCH_CHECK();
+        off += cnt[c];
+    }
     return 0;
 }
 
@@ -525,13 +533,14 @@ extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d
 extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
                                   int n_tiles2, int d, int o, int H, int act, const float* w1, const int* r1,
                                   const int* n1, const float* w2, const int* r2, const int* n2, const long long* coff,
-                                  int B, int maxn, const float* Wb, const float* ZW1, const float* ZW2, const float* wa1,
+                                  int B, const int* order, int n32, int n64, int n96, int n128, const float* Wb,
+                                  const float* ZW1, const float* ZW2, const float* wa1,
                                   const float* wa2, const float* Q2, const float* Z1, const float* Z2, const float* Cbuf,
                                   const float* H1, const float* H2, const float* al1, const float* al2, float* dX1,
                                   float* dX2, float* dWbT, float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws,
                                   size_t ws_floats, hipStream_t st) {
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
-    BMP_REQUIRE(maxn > 0 && maxn <= CO_MAXN);
+    BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && n32 + n64 + n96 + n128 == B);
     BMP_REQUIRE(ws_floats >= bmp_coattn_nie_bwd_ws_floats(n_tiles1, n_tiles2, d, o, H, B));
     const int ZC = bmp_coattn_zcols(o, H);
     const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
@@ -544,21 +553,29 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     // rows outside every pair (dead rows) must read as zero in the GEMMs below
     if ((e = hipMemsetAsync(dQ2, 0, ((size_t)N2 * d + (size_t)(N1 + N2) * ZC) * sizeof(float), st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dX1, 0, (size_t)N1 * d * sizeof(float), st)) != hipSuccess) return (int)e;
-    const int np = (maxn + 31) & ~31;
-    const int ldc = np + 1;
-    const size_t lds = co_lds_floats(np, ldc, H, true) * sizeof(float);
-    BMP_REQUIRE(lds <= 160 * 1024);
     int rc;
     if ((rc = co_set_lds((const void*)k_coattn_bwd, 160 * 1024))) return rc;
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2;
-    a.d = d; a.o = o; a.H = H; a.act = act; a.ldc = ldc;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.order = order;
     a.Cbuf = const_cast<float*>(Cbuf); a.H1 = const_cast<float*>(H1); a.H2 = const_cast<float*>(H2);
     a.al1 = const_cast<float*>(al1); a.al2 = const_cast<float*>(al2);
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
-    hipLaunchKernelGGL(k_coattn_bwd, dim3(B), dim3(256), lds, st, a);
-    BMP_LAUNCH_CHECK();
+    {
+        const int cnt[4] = {n32, n64, n96, n128};
+        int off = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (cnt[c] == 0) continue;
+            a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
+            const size_t lds = co_lds_floats(a.np, a.ldc, H, true) * sizeof(float);
+            BMP_REQUIRE(lds <= 160 * 1024);
+            BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
+            hipLaunchKernelGGL(k_coattn_bwd, dim3(cnt[c]), dim3(256), lds, st, a);
+            BMP_LAUNCH_CHECK();
+            off += cnt[c];
+        }
+    }
     {   // dX1 += dZ1 . ZW1   (K = ZC)
         RGArgs g; memset(&g, 0, sizeof(g));
         g.s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};

@@ -139,7 +139,7 @@ extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, in
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int rows_per_block = 512;
+    const int rows_per_block = 128;
     hipLaunchKernelGGL(k_embed_bwd, dim3((N + rows_per_block - 1) / rows_per_block), dim3(256), lds_bytes, st, ids, dout, N,
                        d, V, rows_per_block, dW);
     BMP_LAUNCH_CHECK();

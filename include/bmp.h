@@ -119,19 +119,22 @@ int bmp_linear_wgrad(const float* X, int ldx, const float* dY, int ldy, int N, i
  * [r1[b], r1[b]+n1[b]) of X1 with rows [r2[b], r2[b]+n2[b]) of X2; w1/w2 are the row multiplicities.
  * WbT[q*d+p] = W[p][q] (bilinear form), ZW{1,2}T [d x ZC] = [Wj^T | Wl_k^T | V_k | 0] with
  * ZC = bmp_coattn_zcols(o, H), zb [ZC] = [bj | 0], wa{1,2} [H], cbias [1].
+ * `order` lists the pair ids grouped by size class (max(n1,n2) <= 32, 64, 96, 128) with n32..n128 the class
+ * counts (sum = B): one launch per class, LDS sized by the class.
  * Saves Q2 [N2 x d], Z1/Z2 [N x ZC], Cbuf (pair b at coff[b]: n2 x n1), H1/H2 [N x H], al1/al2 [N]. */
 int bmp_coattn_zcols(int o, int H);
 int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act,
                        const float* w1, const int* r1, const int* n1, const float* w2, const int* r2, const int* n2,
-                       const long long* coff, int B, int maxn, const float* WbT, const float* ZW1T, const float* ZW2T,
+                       const long long* coff, int B, const int* order, int n32, int n64, int n96, int n128,
+                       const float* WbT, const float* ZW1T, const float* ZW2T,
                        const float* zb, const float* wa1, const float* wa2, const float* cbias, float* Q2, float* Z1,
                        float* Z2, float* Cbuf, float* H1, float* H2, float* al1, float* al2, float* out1, float* out2,
                        bmp_stream_t stream);
 size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B);
 int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
                        int n_tiles2, int d, int o, int H, int act, const float* w1, const int* r1, const int* n1,
-                       const float* w2, const int* r2, const int* n2, const long long* coff, int B, int maxn,
-                       const float* Wb, const float* ZW1, const float* ZW2, const float* wa1, const float* wa2,
+                       const float* w2, const int* r2, const int* n2, const long long* coff, int B, const int* order,
+                       int n32, int n64, int n96, int n128, const float* Wb, const float* ZW1, const float* ZW2, const float* wa1, const float* wa2,
                        const float* Q2, const float* Z1, const float* Z2, const float* Cbuf, const float* H1,
                        const float* H2, const float* al1, const float* al2, float* dX1, float* dX2, float* dWbT,
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
