@@ -97,7 +97,7 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
             float mx = -INFINITY;
             for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
             float s = 0.f;
-            for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) s += L.w2s[i] * expf(L.Cs[i * ldc + j] - mx);
+            for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) s += L.w2s[i] * bmp_exp(L.Cs[i * ldc + j] - mx);
             L.cmax[j] = mx; L.invD2[j] = 1.f / s;
         }
     } else {
@@ -106,7 +106,7 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
             float mx = -INFINITY;
             for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
             float s = 0.f;
-            for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) s += L.w1s[j] * expf(L.Cs[i * ldc + j] - mx);
+            for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) s += L.w1s[j] * bmp_exp(L.Cs[i * ldc + j] - mx);
             L.rmax[i] = mx; L.invD1[i] = 1.f / s;
         }
     }
@@ -115,10 +115,10 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
 // L2[i,j] (softmax over i) and L1[j,i] (softmax over j); zero-weight rows get weight 0 in every sum,
 // so their (possibly huge) exponent is never used.
 __device__ __forceinline__ float co_L2(const CoLds& L, int i, int j, int ldc) {
-    return L.w2s[i] > 0.f ? expf(L.Cs[i * ldc + j] - L.cmax[j]) * L.invD2[j] : 0.f;
+    return L.w2s[i] > 0.f ? bmp_exp(L.Cs[i * ldc + j] - L.cmax[j]) * L.invD2[j] : 0.f;
 }
 __device__ __forceinline__ float co_L1(const CoLds& L, int i, int j, int ldc) {
-    return L.w1s[j] > 0.f ? expf(L.Cs[i * ldc + j] - L.rmax[i]) * L.invD1[i] : 0.f;
+    return L.w1s[j] > 0.f ? bmp_exp(L.Cs[i * ldc + j] - L.rmax[i]) * L.invD1[i] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
@@ -228,11 +228,11 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
         for (int k = lane; k < n; k += 64) if (ww[k] > 0.f) mx = fmaxf(mx, sc[k]);
         mx = wave_max(mx);
         float s = 0.f;
-        for (int k = lane; k < n; k += 64) if (ww[k] > 0.f) s += ww[k] * expf(sc[k] - mx);
+        for (int k = lane; k < n; k += 64) if (ww[k] > 0.f) s += ww[k] * bmp_exp(sc[k] - mx);
         s = wave_sum(s);
         float* alg = wave == 0 ? a.al1 + r1 : a.al2 + r2;
         for (int k = lane; k < n; k += 64) {
-            const float al = ww[k] > 0.f ? expf(sc[k] - mx) / s : 0.f;
+            const float al = ww[k] > 0.f ? bmp_exp(sc[k] - mx) / s : 0.f;
             sc[k] = al;
             alg[k] = al;
         }
