@@ -61,9 +61,11 @@ struct CoLds {
     float* cmax; float* invD2; float* rmax; float* invD1;
     float* s1; float* s2;            // scores / alphas
     float* dots1; float* dots2;
+    float* H1s; float* H2s;          // [np x H] tanh outputs          (backward only)
+    float* do1; float* do2;          // [o] upstream gradients of the pooled outputs (backward only)
 };
 
-__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd) {
+__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd, int o = 0) {
     CoLds L;
     float* p = base;
     L.Cs = p; p += (size_t)np * ldc;
@@ -79,11 +81,15 @@ __device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, b
     L.s1 = p; p += np;
     L.s2 = p; p += np;
     L.dots1 = p; p += np; L.dots2 = p; p += np;
+    L.H1s = p; if (bwd) p += np * H;
+    L.H2s = p; if (bwd) p += np * H;
+    L.do1 = p; if (bwd) p += o;
+    L.do2 = p; if (bwd) p += o;
     return L;
 }
 
-static size_t co_lds_floats(int np, int ldc, int H, bool bwd) {
-    return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 4 : 2) + 11 * (size_t)np + 8;
+static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0) {
+    return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 6 : 2) + 11 * (size_t)np + (bwd ? 2 * (size_t)o : 0) + 8;
 }
 
 // column / row softmax statistics of C with multiplicities:
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-        for (int k0 = 0; k0 < d; k0 += 8) {
+#pragma unroll 8
+        for (int k0 = 0; k0 < d; k0 += 8) {          // unrolled: the 16-byte operand loads of 8 k-steps are in flight together
             const f32x4 av = *(const f32x4*)(qa + k0);
             const f32x4 bv = *(const f32x4*)(xb + k0);
 #pragma unroll
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
         float* out = (side == 0 ? a.out1 : a.out2) + (size_t)b * o;
         for (int c = t; c < o; c += 128) {
             float acc = 0.f;
+#pragma unroll 8
             for (int k = 0; k < n; ++k) acc += ww[k] * al[k] * Z[(size_t)k * ZC + c];
             out[c] = acc;
         }
@@ -264,11 +272,14 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const int n1p = nb1 * 32, n2p = nb2 * 32;
-    const CoLds L = co_carve(lds_raw, a.np, ldc, H, true);
+    const CoLds L = co_carve(lds_raw, a.np, ldc, H, true, o);
 
     // ---- load the pair's saved state ----
     for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n2 * H; idx += 256) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n1 * H; idx += 256) L.H1s[idx] = a.H1[(size_t)r1 * H + idx];
+    for (int idx = tid; idx < n2 * H; idx += 256) L.H2s[idx] = a.H2[(size_t)r2 * H + idx];
+    for (int c = tid; c < o; c += 256) { L.do1[c] = a.dout1[(size_t)b * o + c]; L.do2[c] = a.dout2[(size_t)b * o + c]; }
     if (tid < n1) { L.w1s[tid] = a.w1[r1 + tid]; L.s1[tid] = a.al1[r1 + tid]; }
     if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
         const int i = tid - CO_MAXN;
@@ -282,22 +293,38 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     __syncthreads();
 
     // ---- pooled-output backward: dJ = w*alpha*dout ; dot[k] = J[k,:] . dout ----
-    for (int row = wave; row < n1 + n2; row += 4) {
-        const int side = row < n1 ? 0 : 1;
-        const int k = side == 0 ? row : row - n1;
-        const size_t gr = side == 0 ? (size_t)(r1 + k) : (size_t)(r2 + k);
-        const float* Z = (side == 0 ? a.Z1 : a.Z2) + gr * ZC;
-        float* dZ = (side == 0 ? a.dZ1 : a.dZ2) + gr * ZC;
-        const float* dout = (side == 0 ? a.dout1 : a.dout2) + (size_t)b * o;
-        const float wa = (side == 0 ? L.w1s[k] * L.s1[k] : L.w2s[k] * L.s2[k]);
-        float dot = 0.f;
-        for (int c = lane; c < o; c += 64) {
-            const float g = dout[c];
-            dot += Z[c] * g;
-            dZ[c] = wa * g;
+    {   // each wave takes rows rbase, rbase+4, +8, +12 together: four independent row loads in flight
+        const int nrows = n1 + n2;
+        for (int rbase = wave; rbase < nrows; rbase += 16) {
+            float dot[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = lane; c < o; c += 64) {
+                float zq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rbase + 4 * q;
+                    const size_t gr = row < n1 ? (size_t)(r1 + row) : (size_t)(r2 + row - n1);
+                    zq[q] = row < nrows ? (row < n1 ? a.Z1 : a.Z2)[gr * ZC + c] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = rbase + 4 * q;
+                    if (row < nrows) {
+                        const bool s1 = row < n1;
+                        const int k = s1 ? row : row - n1;
+                        const float g = (s1 ? L.do1 : L.do2)[c];
+                        const float wa = s1 ? L.w1s[k] * L.s1[k] : L.w2s[k] * L.s2[k];
+                        dot[q] += zq[q] * g;
+                        (s1 ? a.dZ1 : a.dZ2)[(size_t)(s1 ? r1 + k : r2 + k) * ZC + c] = wa * g;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rbase + 4 * q;
+                const float dsum = wave_sum(dot[q]);
+                if (lane == 0 && row < nrows) (row < n1 ? L.dots1 : L.dots2)[row < n1 ? row : row - n1] = dsum;
+            }
         }
-        dot = wave_sum(dot);
-        if (lane == 0) (side == 0 ? L.dots1 : L.dots2)[k] = dot;
     }
     __syncthreads();
 
@@ -318,7 +345,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         const int row = idx / H, h = idx % H;
         const int side = row < n1 ? 0 : 1;
         const int k = side == 0 ? row : row - n1;
-        const float hv = side == 0 ? a.H1[(size_t)(r1 + k) * H + h] : a.H2[(size_t)(r2 + k) * H + h];
+        const float hv = (side == 0 ? L.H1s : L.H2s)[k * H + h];
         const float ds = (side == 0 ? L.dots1 : L.dots2)[k];
         const float wa = side == 0 ? a.wa1[h] : a.wa2[h];
         (side == 0 ? L.dH1s : L.dH2s)[k * H + h] = ds * wa * (1.f - hv * hv);
@@ -328,8 +355,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         const int n = side == 0 ? n1 : n2;
         float acc = 0.f;
         for (int k = 0; k < n; ++k) {
-            const float hv = side == 0 ? a.H1[(size_t)(r1 + k) * H + h] : a.H2[(size_t)(r2 + k) * H + h];
-            acc += (side == 0 ? L.dots1 : L.dots2)[k] * hv;
+            acc += (side == 0 ? L.dots1 : L.dots2)[k] * (side == 0 ? L.H1s : L.H2s)[k * H + h];
         }
         a.dpart[(size_t)b * (2 * H + 1) + side * H + h] = acc;
     }
@@ -432,6 +458,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll 4
         for (int k0 = 0; k0 < knp; k0 += 8) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -568,7 +595,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
         for (int c = 0; c < 4; ++c) {
             if (cnt[c] == 0) continue;
             a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
-            const size_t lds = co_lds_floats(a.np, a.ldc, H, true) * sizeof(float);
+            const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o) * sizeof(float);
             BMP_REQUIRE(lds <= 160 * 1024);
             BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
             hipLaunchKernelGGL(k_coattn_bwd, dim3(cnt[c]), dim3(256), lds, st, a);
