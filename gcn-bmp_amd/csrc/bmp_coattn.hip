@@ -63,6 +63,7 @@ struct CoLds {
     float* dots1; float* dots2;
     float* H1s; float* H2s;          // [np x H] tanh outputs          (backward only)
     float* do1; float* do2;          // [o] upstream gradients of the pooled outputs (backward only)
+    float* Up; float* dPp; float* cmb;   // [256], [256 x H], [np] per-thread partial sums / combined row sums (backward)
 };
 
 __device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd, int o = 0) {
@@ -85,11 +86,16 @@ __device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, b
     L.H2s = p; if (bwd) p += np * H;
     L.do1 = p; if (bwd) p += o;
     L.do2 = p; if (bwd) p += o;
+    L.cmb = p; if (bwd) p += np;
+    // np == 128: SUB = 2, and the slots alias arrays that are dead by then (dots1|dots2 = 256, H1s|H2s = 256 x H)
+    if (np >= 128) { L.Up = L.dots1; L.dPp = L.H1s; }
+    else { L.Up = p; if (bwd) p += 256; L.dPp = p; if (bwd) p += 256 * H; }
     return L;
 }
 
 static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0) {
-    return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 6 : 2) + 11 * (size_t)np + (bwd ? 2 * (size_t)o : 0) + 8;
+    return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 6 : 2) + 11 * (size_t)np + (bwd ? 2 * (size_t)o + np : 0) +
+           ((bwd && np < 128) ? 256 + 256 * (size_t)H : 0) + 8;
 }
 
 // column / row softmax statistics of C with multiplicities:
@@ -127,13 +133,15 @@ __device__ __forceinline__ float co_L1(const CoLds& L, int i, int j, int ldc) {
     return L.w1s[j] > 0.f ? bmp_exp(L.Cs[i * ldc + j] - L.rmax[i]) * L.invD1[i] : 0.f;
 }
 
+template <int HT>
 __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
+    constexpr int HN = HT > 0 ? HT : CO_MAXH;       // head count known at compile time (8, 4) or runtime (<16)
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const int b = a.order[a.order_off + blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
-    const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
+    const int d = a.d, o = a.o, H = HT > 0 ? HT : a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const CoLds L = co_carve(lds_raw, a.np, ldc, H, false);
     const float cb = a.cbias[0];
@@ -186,17 +194,17 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     if (tid < CO_MAXN) {
         const int j = tid;
         if (j < n1) {
-            float acc[CO_MAXH];
+            float acc[HN];
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) acc[h] = 0.f;
+            for (int h = 0; h < HN; ++h) acc[h] = 0.f;
             for (int i = 0; i < n2; ++i) {
                 const float e = L.w2s[i] * co_L1(L, i, j, ldc);
 #pragma unroll
-                for (int h = 0; h < CO_MAXH; ++h) if (h < H) acc[h] += e * L.P2s[i * H + h];
+                for (int h = 0; h < HN; ++h) if (h < H) acc[h] += e * L.P2s[i * H + h];
             }
             float s = 0.f;
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+            for (int h = 0; h < HN; ++h) if (h < H) {
                 const float hv = bmp_tanh(L.P1s[j * H + h] + acc[h]);
                 a.H1[(size_t)(r1 + j) * H + h] = hv;
                 s += hv * a.wa1[h];
@@ -206,17 +214,17 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     } else {
         const int i = tid - CO_MAXN;
         if (i < n2) {
-            float acc[CO_MAXH];
+            float acc[HN];
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) acc[h] = 0.f;
+            for (int h = 0; h < HN; ++h) acc[h] = 0.f;
             for (int j = 0; j < n1; ++j) {
                 const float e = L.w1s[j] * co_L2(L, i, j, ldc);
 #pragma unroll
-                for (int h = 0; h < CO_MAXH; ++h) if (h < H) acc[h] += e * L.P1s[j * H + h];
+                for (int h = 0; h < HN; ++h) if (h < H) acc[h] += e * L.P1s[j * H + h];
             }
             float s = 0.f;
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+            for (int h = 0; h < HN; ++h) if (h < H) {
                 const float hv = bmp_tanh(L.P2s[i * H + h] + acc[h]);
                 a.H2[(size_t)(r2 + i) * H + h] = hv;
                 s += hv * a.wa2[h];
@@ -263,13 +271,15 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     }
 }
 
+template <int HT>
 __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
+    constexpr int HN = HT > 0 ? HT : CO_MAXH;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const int b = a.order[a.order_off + blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
-    const int d = a.d, o = a.o, H = a.H, ZC = a.ZC, ldc = a.ldc;
+    const int d = a.d, o = a.o, H = HT > 0 ? HT : a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const int n1p = nb1 * 32, n2p = nb2 * 32;
     const CoLds L = co_carve(lds_raw, a.np, ldc, H, true, o);
@@ -362,76 +372,135 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     co_stats(L, n1, n2, ldc);
     __syncthreads();
 
-    // ---- softmax-of-C backward.  L1 path (threads over i) writes dS, then the L2 path (threads over j)
-    //      adds its part and applies act'(C).  dP1/dP2 fall out of the same loops. ----
-    if (tid >= CO_MAXN) {
-        const int i = tid - CO_MAXN;
-        if (i < n2) {
-            float p2[CO_MAXH], dp2[CO_MAXH];
+    // ---- softmax-of-C backward, all 256 threads: thread (row, q) owns the q-th chunk of the other side's atoms.
+    //      L1[j,i] = softmax over j (row i fixed):  dC1[i,j] = L1*(w2_i*g1[i,j] - w1_j*U1_i),  g1 = dH1[j,:].P2[i,:],
+    //      U1_i = sum_j L1*w2_i*g1 ;  dP2[i,:] = dH2[i,:] + w2_i * sum_j L1 * dH1[j,:]      (and symmetrically L2).
+    //      Partial sums go to per-thread LDS slots and are combined in a fixed order (reproducible). ----
+    const int np_ = a.np;
+    const int SUB = 256 / np_;
+    const int prow = tid % np_, pq = tid / np_;
+    {   // L1 path, pass 1
+        float U = 0.f, dp[HN];
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) { p2[h] = h < H ? L.P2s[i * H + h] : 0.f; dp2[h] = h < H ? L.dH2s[i * H + h] : 0.f; }
+        for (int h = 0; h < HN; ++h) dp[h] = 0.f;
+        if (pq < SUB && prow < n2) {
+            const int i = prow;
+            const int chunk = (n1 + SUB - 1) / SUB, j0 = pq * chunk, j1 = (j0 + chunk) < n1 ? (j0 + chunk) : n1;
+            float p2[HN];
+#pragma unroll
+            for (int h = 0; h < HN; ++h) p2[h] = h < H ? L.P2s[i * H + h] : 0.f;
             const float w2i = L.w2s[i];
-            float U = 0.f;
-            for (int j = 0; j < n1; ++j) {
+            for (int j = j0; j < j1; ++j) {
                 const float l1 = co_L1(L, i, j, ldc);
                 float g = 0.f;
 #pragma unroll
-                for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+                for (int h = 0; h < HN; ++h) if (h < H) {
                     const float dh = L.dH1s[j * H + h];
                     g += dh * p2[h];
-                    dp2[h] += w2i * l1 * dh;
+                    dp[h] += w2i * l1 * dh;
                 }
                 U += l1 * (w2i * g);
             }
-            for (int j = 0; j < n1; ++j) {
-                const float l1 = co_L1(L, i, j, ldc);
-                float g = 0.f;
+        }
+        L.Up[tid] = U;
 #pragma unroll
-                for (int h = 0; h < CO_MAXH; ++h) if (h < H) g += L.dH1s[j * H + h] * p2[h];
-                L.dSs[i * ldc + j] = l1 * (w2i * g) - L.w1s[j] * l1 * U;
-            }
+        for (int h = 0; h < HN; ++h) if (h < H) L.dPp[tid * H + h] = dp[h];
+    }
+    __syncthreads();
+    if (tid < n2) {          // U1_i in a fixed order
+        float u = 0.f;
+        for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + tid];
+        L.cmb[tid] = u;
+    }
+    for (int idx = tid; idx < n2 * H; idx += 256) {       // dP2 -> dZ2
+        const int i = idx / H, h = idx % H;
+        float v = L.dH2s[idx];
+        for (int q = 0; q < SUB; ++q) v += L.dPp[(q * np_ + i) * H + h];
+        a.dZ2[(size_t)(r2 + i) * ZC + o + h] = v;
+    }
+    __syncthreads();
+    if (pq < SUB && prow < n2) {   // L1 path, pass 2: dS <- dC1
+        const int i = prow;
+        const int chunk = (n1 + SUB - 1) / SUB, j0 = pq * chunk, j1 = (j0 + chunk) < n1 ? (j0 + chunk) : n1;
+        float p2[HN];
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) if (h < H) a.dZ2[(size_t)(r2 + i) * ZC + o + h] = dp2[h];
+        for (int h = 0; h < HN; ++h) p2[h] = h < H ? L.P2s[i * H + h] : 0.f;
+        const float w2i = L.w2s[i], U = L.cmb[i];
+        for (int j = j0; j < j1; ++j) {
+            const float l1 = co_L1(L, i, j, ldc);
+            float g = 0.f;
+#pragma unroll
+            for (int h = 0; h < HN; ++h) if (h < H) g += L.dH1s[j * H + h] * p2[h];
+            L.dSs[i * ldc + j] = l1 * (w2i * g) - L.w1s[j] * l1 * U;
         }
     }
     __syncthreads();
-    if (tid < CO_MAXN) {
-        const int j = tid;
-        if (j < n1) {
-            float p1[CO_MAXH], dp1[CO_MAXH];
+    {   // L2 path, pass 1
+        float U = 0.f, dp[HN];
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) { p1[h] = h < H ? L.P1s[j * H + h] : 0.f; dp1[h] = h < H ? L.dH1s[j * H + h] : 0.f; }
+        for (int h = 0; h < HN; ++h) dp[h] = 0.f;
+        if (pq < SUB && prow < n1) {
+            const int j = prow;
+            const int chunk = (n2 + SUB - 1) / SUB, i0 = pq * chunk, i1 = (i0 + chunk) < n2 ? (i0 + chunk) : n2;
+            float p1[HN];
+#pragma unroll
+            for (int h = 0; h < HN; ++h) p1[h] = h < H ? L.P1s[j * H + h] : 0.f;
             const float w1j = L.w1s[j];
-            float U = 0.f;
-            for (int i = 0; i < n2; ++i) {
+            for (int i = i0; i < i1; ++i) {
                 const float l2 = co_L2(L, i, j, ldc);
                 float g = 0.f;
 #pragma unroll
-                for (int h = 0; h < CO_MAXH; ++h) if (h < H) {
+                for (int h = 0; h < HN; ++h) if (h < H) {
                     const float dh = L.dH2s[i * H + h];
                     g += dh * p1[h];
-                    dp1[h] += w1j * l2 * dh;
+                    dp[h] += w1j * l2 * dh;
                 }
                 U += l2 * (w1j * g);
             }
-            float dv1 = 0.f;
-            for (int i = 0; i < n2; ++i) {
-                const float l2 = co_L2(L, i, j, ldc);
-                float g = 0.f;
+        }
+        L.Up[tid] = U;
 #pragma unroll
-                for (int h = 0; h < CO_MAXH; ++h) if (h < H) g += L.dH2s[i * H + h] * p1[h];
-                const float dc = L.dSs[i * ldc + j] + l2 * (w1j * g) - L.w2s[i] * l2 * U;
-                const float ds = dc * bmp_dact(a.act, L.Cs[i * ldc + j]);
-                L.dSs[i * ldc + j] = ds;
-                dv1 += ds;
-            }
+        for (int h = 0; h < HN; ++h) if (h < H) L.dPp[tid * H + h] = dp[h];
+    }
+    __syncthreads();
+    if (tid < n1) {
+        float u = 0.f;
+        for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + tid];
+        L.cmb[tid] = u;
+    }
+    for (int idx = tid; idx < n1 * H; idx += 256) {       // dP1 -> dZ1
+        const int j = idx / H, h = idx % H;
+        float v = L.dH1s[idx];
+        for (int q = 0; q < SUB; ++q) v += L.dPp[(q * np_ + j) * H + h];
+        a.dZ1[(size_t)(r1 + j) * ZC + o + h] = v;
+    }
+    __syncthreads();
+    if (pq < SUB && prow < n1) {   // L2 path, pass 2: dS <- (dC1 + dC2) * act'(C)
+        const int j = prow;
+        const int chunk = (n2 + SUB - 1) / SUB, i0 = pq * chunk, i1 = (i0 + chunk) < n2 ? (i0 + chunk) : n2;
+        float p1[HN];
 #pragma unroll
-            for (int h = 0; h < CO_MAXH; ++h) if (h < H) a.dZ1[(size_t)(r1 + j) * ZC + o + h] = dp1[h];
-            a.dZ1[(size_t)(r1 + j) * ZC + o + H] = dv1;
+        for (int h = 0; h < HN; ++h) p1[h] = h < H ? L.P1s[j * H + h] : 0.f;
+        const float w1j = L.w1s[j], U = L.cmb[j];
+        for (int i = i0; i < i1; ++i) {
+            const float l2 = co_L2(L, i, j, ldc);
+            float g = 0.f;
+#pragma unroll
+            for (int h = 0; h < HN; ++h) if (h < H) g += L.dH2s[i * H + h] * p1[h];
+            const float dc = L.dSs[i * ldc + j] + l2 * (w1j * g) - L.w2s[i] * l2 * U;
+            L.dSs[i * ldc + j] = dc * bmp_dact(a.act, L.Cs[i * ldc + j]);
         }
     }
     __syncthreads();
-    if (tid >= CO_MAXN) {          // dv2[i] = sum_j dS[i,j] ; dc = sum_i dv2[i]
+    // dv1[j] = sum_i dS[i,j] ; dv2[i] = sum_j dS[i,j] ; dc = sum_i dv2[i]
+    if (tid < CO_MAXN) {
+        const int j = tid;
+        if (j < n1) {
+            float dv1 = 0.f;
+            for (int i = 0; i < n2; ++i) dv1 += L.dSs[i * ldc + j];
+            a.dZ1[(size_t)(r1 + j) * ZC + o + H] = dv1;
+        }
+    } else {
         const int i = tid - CO_MAXN;
         float dv2 = 0.f;
         if (i < n2) {
@@ -517,7 +586,8 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         g.nsrc = 1; g.Nout = ZC; g.Y = s == 0 ? Z1 : Z2; g.ldy = ZC; g.bias = zb;
         if ((rc = bmp_launch_rowgemm(g, s == 0 ? n_tiles1 : n_tiles2, BMP_EPI_GENERIC, st))) return rc;
     }
-    if ((rc = co_set_lds((const void*)k_coattn_fwd, 160 * 1024))) return rc;
+    const void* kf = H == 8 ? (const void*)k_coattn_fwd<8> : H == 4 ? (const void*)k_coattn_fwd<4> : (const void*)k_coattn_fwd<0>;
+    if ((rc = co_set_lds(kf, 160 * 1024))) return rc;
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
@@ -532,7 +602,9 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         const size_t lds = co_lds_floats(a.np, a.ldc, H, false) * sizeof(float);
         BMP_REQUIRE(lds <= 160 * 1024);
         BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
-        hipLaunchKernelGGL(k_coattn_fwd, dim3(cnt[c]), dim3(256), lds, st, a);
+        if (H == 8) hipLaunchKernelGGL(k_coattn_fwd<8>, dim3(cnt[c]), dim3(256), lds, st, a);
+        else if (H == 4) hipLaunchKernelGGL(k_coattn_fwd<4>, dim3(cnt[c]), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(k_coattn_fwd<0>, dim3(cnt[c]), dim3(256), lds, st, a);
         BMP_LAUNCH_CHECK();
         off += cnt[c];
     }
@@ -581,7 +653,8 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     if ((e = hipMemsetAsync(dQ2, 0, ((size_t)N2 * d + (size_t)(N1 + N2) * ZC) * sizeof(float), st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dX1, 0, (size_t)N1 * d * sizeof(float), st)) != hipSuccess) return (int)e;
     int rc;
-    if ((rc = co_set_lds((const void*)k_coattn_bwd, 160 * 1024))) return rc;
+    const void* kb = H == 8 ? (const void*)k_coattn_bwd<8> : H == 4 ? (const void*)k_coattn_bwd<4> : (const void*)k_coattn_bwd<0>;
+    if ((rc = co_set_lds(kb, 160 * 1024))) return rc;
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2;
@@ -598,7 +671,9 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
             const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o) * sizeof(float);
             BMP_REQUIRE(lds <= 160 * 1024);
             BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
-            hipLaunchKernelGGL(k_coattn_bwd, dim3(cnt[c]), dim3(256), lds, st, a);
+            if (H == 8) hipLaunchKernelGGL(k_coattn_bwd<8>, dim3(cnt[c]), dim3(256), lds, st, a);
+            else if (H == 4) hipLaunchKernelGGL(k_coattn_bwd<4>, dim3(cnt[c]), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL(k_coattn_bwd<0>, dim3(cnt[c]), dim3(256), lds, st, a);
             BMP_LAUNCH_CHECK();
             off += cnt[c];
         }
