@@ -40,29 +40,40 @@ struct StepArgs {
 // acc[nb][rb] += A(rows of this wave, K) . B_nb(K, 32 cols)   with A in LDS, B streamed from global.
 //   As_wave = &tile[(wave_row0 + (lane & 31)) * LD + 4 * (lane >> 5)]
 //   Bp[nb]  = B_nb + 4 * (lane >> 5) * ldw[nb] + col      (col = this lane's output column)
+// `rot` (multiple of 8, < K) rotates the K loop: workgroups walk the shared weight matrices from different
+// starting rows, so the 256 CUs do not all request the same L2 lines at the same moment.
 template <int NB, int RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K) {
-    f32x4 bc[NB], bn[NB];
+                                         const int (&ldw)[NB], int K, int rot) {
+    // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
+    // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
+    // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
+    f32x4 b0[NB], b1[NB], b2[NB];
+    int k = rot;
+    int k1 = k + 8; if (k1 >= K) k1 -= K;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bc[nb] = *(const f32x4*)(Bp[nb]);
-#pragma unroll 2
-    for (int kk = 0; kk < K; kk += 8) {
-        if (kk + 8 < K) {
+    for (int nb = 0; nb < NB; ++nb) {
+        b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)k * ldw[nb]);
+        b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
+    }
+    for (int it = 0; it < K; it += 8) {
+        int k2 = k1 + 8; if (k2 >= K) k2 -= K;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bn[nb] = *(const f32x4*)(Bp[nb] + (size_t)(kk + 8) * ldw[nb]);
-        }
+        for (int nb = 0; nb < NB; ++nb) b2[nb] = *(const f32x4*)(Bp[nb] + (size_t)k2 * ldw[nb]);
         f32x4 av[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) av[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + kk);
+        for (int rb = 0; rb < RB; ++rb) av[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(av[rb][t], bc[nb][t], acc[nb][rb]);
+                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(av[rb][t], b0[nb][t], acc[nb][rb]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bc[nb] = bn[nb];
+        for (int nb = 0; nb < NB; ++nb) { b0[nb] = b1[nb]; b1[nb] = b2[nb]; }
+        k = k1; k1 = k2;
     }
 }
 
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;         // this lane's row for reg 0 of row block 0
+    const int rot = (blockIdx.x * 8) % D;
     const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
     const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
     float* Hl = Hs + lrow * LD + col;        // accumulator-layout views of the two LDS tiles
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         if (any) {
             const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
             const int ldw[1] = {D};
-            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D);
+            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot);
         }
         __syncthreads();
     }
@@ -228,15 +240,15 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const int ldw2[2] = {3 * D, 3 * D};
             const float* const Bh[2] = {base_h + 4 * D, base_h + 8 * D};
             const float* const Bm[2] = {base_m + 4 * D, base_m + 8 * D};
-            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D);
-            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D);
+            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D, rot);
+            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D, rot);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) { acc_g[1][rb] = g2[0][rb]; acc_g[2][rb] = g2[1][rb]; }
         } else {
             const float* const Bh[3] = {base_h, base_h + 4 * D, base_h + 8 * D};
             const float* const Bm[3] = {base_m, base_m + 4 * D, base_m + 8 * D};
-            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D);
-            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D);
+            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D, rot);
+            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D, rot);
         }
     }
     const float br = a.b[col], bz = a.b[D + col], bcn = a.b[2 * D + col];
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
         const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
         const int ldu[1] = {D};
-        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D);
+        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
     }
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
+    const int rot = (blockIdx.x * 8) % D;
     const float* Xw = Xs + (wrow0 + l31) * LD + 4 * hi;
     const float* Yw = Ys + (wrow0 + l31) * LD + 4 * hi;
     float* Xl = Xs + lrow * LD + col;
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     const int ld2[2] = {2 * D, 2 * D};
     {   // [dh | dm] += da_c . A_c
         const float* const Bc[2] = {Ac_h, Ac_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D);
+        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot);
     }
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         {
             const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
-            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D);
+            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot);
         }
         __syncthreads();                     // all waves done with da_c in X
         // da_r = d(r*h) * h * r * (1-r) -> X ; dh += d(r*h) * r
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         __syncthreads();
         {   // X = da_r
             const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
-            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D);
+            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot);
         }
     }
     __syncthreads();
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     __syncthreads();
     {
         const float* const Bz[2] = {Az_h, Az_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Xw, LD, Bz, ld2, D);
+        tile_mma<2, RB>(acc_x, Xw, LD, Bz, ld2, D, rot);
     }
     __syncthreads();                         // all waves done with X
     // ---- X <- dm ----
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         if (any) {
             const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
             const int ldw[1] = {4 * D};
-            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D);
+            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot);
         }
         __syncthreads();
     }

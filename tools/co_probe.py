@@ -15,8 +15,8 @@ def run():
     y = model(pb); loss = model.loss(y, t); loss.backward()
 for _ in range(3): run()
 torch.cuda.synchronize()
-L.bmp_prof_start(4)
+L.bmp_prof_start(int(os.environ.get("KCLS", "4")))
 for _ in range(5): run()
 torch.cuda.synchronize()
 n = L.bmp_prof_stop(out)
-print('stop', os.environ.get('BMP_CO_STOP'), 'coattn class ms/step', out[0] / 5, 'launches/step', n / 5)
+print('stop', os.environ.get('BMP_FZ_STOP'), 'coattn class ms/step', out[0] / 5, 'launches/step', n / 5)
