@@ -56,23 +56,27 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
         b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)k * ldw[nb]);
         b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
     }
+    f32x4 a0[RB], a1[RB];            // A fragments (LDS) run one k-step ahead
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) a0[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
     for (int it = 0; it < K; it += 8) {
         int k2 = k1 + 8; if (k2 >= K) k2 -= K;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b2[nb] = *(const f32x4*)(Bp[nb] + (size_t)k2 * ldw[nb]);
-        f32x4 av[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) av[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
+        for (int rb = 0; rb < RB; ++rb) a1[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(av[rb][t], b0[nb][t], acc[nb][rb]);
+                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(a0[rb][t], b0[nb][t], acc[nb][rb]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { b0[nb] = b1[nb]; b1[nb] = b2[nb]; }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a0[rb] = a1[rb];
         k = k1; k1 = k2;
     }
 }

@@ -326,23 +326,31 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         if (st + 1 < nst) { WG_LOAD(st + 1) }
+        // fragments of k-step s+1 are read from LDS (pinned by scheduling barriers) before the 16 MFMAs of
+        // k-step s issue: otherwise every MFMA waits on its own ds_read
+        float av[2][2][4], bv[2][2][4];
+#define WG_FRAG(slot, k0)                                                                              \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+            av[slot][m][t] = XS[buf][(k0) + 4 * hi + t][wm * 64 + m * 32 + l31];                       \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                  \
+            bv[slot][n][t] = YS[buf][(k0) + 4 * hi + t][wn * 64 + n * 32 + l31];                       \
+    }
+        WG_FRAG(0, 0)
 #pragma unroll
-        for (int k0 = 0; k0 < 32; k0 += 8) {
-            float av[2][4], bv[2][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) av[m][t] = XS[buf][k0 + 4 * hi + t][wm * 64 + m * 32 + l31];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) bv[n][t] = YS[buf][k0 + 4 * hi + t][wn * 64 + n * 32 + l31];
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 4) { WG_FRAG(cur ^ 1, (ks + 1) * 8) }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[m][t], bv[n][t], acc[m][n]);
+                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t], bv[cur][n][t], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef WG_FRAG
         if (st + 1 < nst) { WG_STORE(buf ^ 1) }
         __syncthreads();
     }
