@@ -145,10 +145,10 @@ def main():
 
     def step(i):
         pb, t = batches[i % N_DISTINCT_BATCHES]
-        opt.zero_grad()
-        y = model(pb)
+        y = opt.functional_forward(pb)          # parameters = views of the flat buffer, ONE gradient tensor
         loss = model.loss(y, t)
         loss.backward()
+        opt.collect_grads()
         opt.all_reduce_grads()
         opt.step()
         return loss

@@ -99,8 +99,7 @@ class NieCoattnFn(Function):
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         Q2, Z1, Z2 = f(N2, d), f(N1, ZC), f(N2, ZC)
         Cbuf = f(max(meta["ctotal"], 1))
-        H1, H2 = torch.zeros(N1, H, device=dev), torch.zeros(N2, H, device=dev)
-        al1, al2 = torch.zeros(N1, device=dev), torch.zeros(N2, device=dev)
+        H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)      # written / read only at rows that belong to a pair
         out1, out2 = f(B, o), f(B, o)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
                                    ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order"]),

@@ -14,6 +14,38 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 from torch import nn
+from torch.autograd import Function
+
+
+class _Unflatten(Function):
+    """flat parameter buffer -> the individual parameter tensors (views).  The backward writes all
+    parameter gradients into ONE flat tensor with a single concatenation, instead of one
+    accumulate kernel per parameter."""
+
+    @staticmethod
+    def forward(ctx, flat, shapes):
+        ctx.shapes = shapes
+        outs, off = [], 0
+        for shp in shapes:
+            n = 1
+            for k in shp:
+                n *= k
+            outs.append(flat[off:off + n].view(shp))
+            off += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        parts = []
+        for g, shp in zip(grads, ctx.shapes):
+            if g is None:
+                n = 1
+                for k in shp:
+                    n *= k
+                parts.append(grads[0].new_zeros(n) if grads[0] is not None else torch.zeros(n))
+            else:
+                parts.append(g.reshape(-1))
+        return torch.cat(parts), None
 
 
 class FlatAdam:
@@ -38,6 +70,9 @@ class FlatAdam:
             p.grad = self.grad[off:off + n].view_as(p)
             off += n
         self.params = params
+        self.names = [n for n, p in module.named_parameters() if p.requires_grad]
+        self.shapes = [tuple(p.shape) for p in params]
+        self.module = module
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.t = 0
@@ -47,6 +82,20 @@ class FlatAdam:
 
     def zero_grad(self) -> None:
         self.grad.zero_()
+
+    # ---- functional mode: one gradient tensor for the whole model, no per-parameter accumulation ----
+    def functional_forward(self, *args, **kwargs):
+        """Run the module on parameter views produced by ONE autograd node over the flat buffer.
+        After ``loss.backward()`` call ``collect_grads()``; the flat gradient is then in ``self.grad``."""
+        leaf = self.flat.detach().requires_grad_()
+        self._leaf = leaf
+        views = _Unflatten.apply(leaf, self.shapes)
+        return torch.func.functional_call(self.module, dict(zip(self.names, views)), args, kwargs)
+
+    def collect_grads(self) -> None:
+        g = self._leaf.grad
+        self.grad = g if g is not None else torch.zeros_like(self.flat)
+        self._leaf = None
 
     def reattach(self) -> None:
         """Fold any .grad tensor that autograd (or a caller) replaced back into the flat buffer."""

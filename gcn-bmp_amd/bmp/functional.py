@@ -196,6 +196,9 @@ class GGNNStepFn(Function):
                                   stream()), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, WT, AT, UcT, m, rz, c)
         ctx.pb, ctx.first, ctx.cache = pb, int(first), cache
+        if cache is not None:       # how many steps of this call share both weight sets (see backward)
+            key = ("n", WT.data_ptr(), AT.data_ptr())
+            cache[key] = cache.get(key, 0) + 1
         return hout
 
     @staticmethod
@@ -214,11 +217,27 @@ class GGNNStepFn(Function):
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(A), ptr(Uc), ptr(dh), ptr(gda),
                                   stream()), "bmp_ggnn_step_bwd")
-        o1, o2, dUcT, cs = f(d, 7 * d), f(d, 3 * d), f(d, d), f(7 * d)
+        # Steps that share BOTH weight sets (tied layers) accumulate their weight gradients in one set of
+        # buffers inside the kernels; only the last of them to run hands the sums to autograd.
+        grp = ("g", WT.data_ptr(), AT.data_ptr())
+        st = None
+        if cache is not None and cache.get(("n",) + grp[1:], 1) > 1:
+            st = cache.setdefault(grp, dict(seen=0, buf=None))
+        if st is None or st["buf"] is None:
+            o1, o2, dUcT, cs = f(d, 7 * d), f(d, 3 * d), f(d, d), f(7 * d)
+            if st is not None:
+                st["buf"] = (o1, o2, dUcT, cs)
+        else:
+            o1, o2, dUcT, cs = st["buf"]
+        acc = 1 if (st is not None and st["seen"] > 0) else 0
         nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
         ws = _ws(nws, dev)
         check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(o1), ptr(o2), ptr(dUcT), ptr(cs),
-                                    0, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+                                    acc, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+        if st is not None:
+            st["seen"] += 1
+            if st["seen"] < cache[("n",) + grp[1:]]:
+                return dh, None, None, None, None, None, None, None, None
         dWT = o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)      # [k][e*d+c] -> [e*d+k][c]
         dbE = cs[:4 * d].reshape(4, d)
         dAT = torch.cat((o1[:, 4 * d:], o2), dim=0)

@@ -118,3 +118,22 @@ def test_parameters_are_views_of_the_flat_buffer():
 
 def test_shard_partitions_the_batch():
     assert [shard(8192, r, 8) for r in range(8)] == [slice(1024 * r, 1024 * (r + 1)) for r in range(8)]
+
+
+def test_functional_mode_matches_per_parameter_grads():
+    """One flat gradient via a single autograd node == the per-parameter .grad views."""
+    x, t = _data()
+    m1, m2 = _model(), _model()
+    o1, o2 = FlatAdam(m1, alpha=1e-2), FlatAdam(m2, alpha=1e-2)
+    for _ in range(3):
+        o1.zero_grad()
+        sigmoid_cross_entropy(m1(x), t).backward()
+        o1.step()
+        loss = sigmoid_cross_entropy(o2.functional_forward(x), t)
+        loss.backward()
+        o2.collect_grads()
+        assert torch.allclose(o1.grad, o2.grad, rtol=1e-6, atol=1e-8)
+        o2.step()
+    assert torch.allclose(o1.flat, o2.flat, rtol=1e-6, atol=1e-8)
+    for p, q in zip(m1.parameters(), m2.parameters()):       # module parameters stay views of the flat buffer
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-8)
