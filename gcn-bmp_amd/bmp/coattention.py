@@ -87,7 +87,7 @@ class NieCoattnFn(Function):
     """bmp_coattn_nie_fwd / _bwd.  Inputs in kernel layout (see include/bmp.h)."""
 
     @staticmethod
-    def forward(ctx, X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cbias, w1, w2, meta, d, o, H, act):
+    def forward(ctx, X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cbias, w1, w2, meta, d, o, H, act, mode=0):
         L = _lib.lib()
         dev = X1.device
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
@@ -101,13 +101,13 @@ class NieCoattnFn(Function):
         Cbuf = f(max(meta["ctotal"], 1))
         H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)      # written / read only at rows that belong to a pair
         out1, out2 = f(B, o), f(B, o)
-        check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
+        check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
                                    ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order"]),
                                    *meta["counts"], ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
                                    ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(out1),
                                    ptr(out2), stream()), "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
-        ctx.meta, ctx.dims = meta, (d, o, H, act, ZC)
+        ctx.meta, ctx.dims = meta, (d, o, H, act, ZC, mode)
         return out1, out2
 
     @staticmethod
@@ -115,7 +115,7 @@ class NieCoattnFn(Function):
         L = _lib.lib()
         X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2 = ctx.saved_tensors
         meta = ctx.meta
-        d, o, H, act, ZC = ctx.dims
+        d, o, H, act, ZC, mode = ctx.dims
         dev = X1.device
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         dout1, dout2 = dout1.contiguous(), dout2.contiguous()
@@ -126,7 +126,7 @@ class NieCoattnFn(Function):
         dWbT, dZW1T, dZW2T, dzb, dwa = f(d, d), f(d, ZC), f(d, ZC), f(ZC), f(2 * H + 1)
         nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
         ws = _ws(nws, dev)
-        check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, ptr(w1),
+        check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1),
                                    ptr(meta["r1"]), ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]),
                                    ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], ptr(Wb), ptr(ZW1), ptr(ZW2), ptr(wa1),
                                    ptr(wa2),
@@ -134,7 +134,7 @@ class NieCoattnFn(Function):
                                    ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
                                    stream()), "bmp_coattn_nie_bwd")
         return (dX1, dX2, dWbT, dZW1T, dZW2T, dzb, dwa[:H], dwa[H:2 * H], dwa[2 * H:], None, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 class NieFineCoattention(nn.Module):
@@ -185,3 +185,38 @@ class VQAParallelCoattention(NieFineCoattention):
 
     def __init__(self, hidden_dim, out_dim, head, activation="tanh"):
         super().__init__(hidden_dim, out_dim, head, activation)
+
+
+class PoolingFineCoattention(nn.Module):
+    """models/coattention/PoolingFineCoattention.py:13-81: same bilinear energy C as Nie; the atom
+    weights are softmax(mean of C over the other side's padded positions); no head projections."""
+
+    def __init__(self, hidden_dim, out_dim, activation="tanh"):
+        super().__init__()
+        if hidden_dim % 8 or out_dim % 4:
+            raise ValueError("hidden_dim must be a multiple of 8 and out_dim of 4")
+        self.energy_layer = Bilinear(hidden_dim, hidden_dim, 1)
+        self.j_layer = Linear(hidden_dim, out_dim)
+        self.hidden_dim, self.out_dim = hidden_dim, out_dim
+        if callable(activation):
+            activation = getattr(activation, "__name__", str(activation))
+        if activation not in ("identity", "tanh", "sigmoid", "relu"):
+            raise ValueError(f"unsupported activation {activation!r}")
+        self.activation = activation
+
+    def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
+        if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
+            raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        X1, X2, w1, w2, meta, _joint = pair_rows(atoms_1, atoms_2)
+        d, o, H = self.hidden_dim, self.out_dim, 1          # one (unused, zero-weight) head column keeps the row layout
+        ZC = _lib.lib().bmp_coattn_zcols(o, H)
+        E = self.energy_layer
+        dev = E.W.device
+        pad = torch.zeros(d, ZC - o - H - 1, device=dev)
+        zcol = torch.zeros(d, H, device=dev)
+        ZW1T = torch.cat((self.j_layer.W.t(), zcol, E.V1, pad), dim=1)
+        ZW2T = torch.cat((self.j_layer.W.t(), zcol, E.V2, pad), dim=1)
+        zb = torch.cat((self.j_layer.b, torch.zeros(ZC - o, device=dev)))
+        wa = torch.zeros(H, device=dev)
+        return NieCoattnFn.apply(X1, X2, E.W[:, :, 0].t(), ZW1T, ZW2T, zb, wa, wa, E.b, w1, w2, meta, d, o, H,
+                                 ACT[self.activation], 1)

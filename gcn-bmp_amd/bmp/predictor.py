@@ -85,6 +85,9 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
     if attn in ("nie", "vqa"):
         from .coattention import NieFineCoattention
         a = NieFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
+    elif attn == "pool":
+        from .coattention import PoolingFineCoattention
+        a = PoolingFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim)       # train_binary.py:210-212
     elif attn is not None:
         raise ValueError('[ERROR] Invalid Co-Attention Method.')
     return GraphConvPredictorForPair(enc, a, MLP(class_num, mlp_hidden, in_dim=2 * out_dim))

@@ -27,6 +27,7 @@ struct CoArgs {
     int np;                                    // class size: every pair of this launch has n1, n2 <= np (multiple of 32)
     const float* wa1; const float* wa2; const float* cbias;
     int d, o, H, act, ldc;
+    int mode;                                  // 0 = Nie/VQA (softmaxes of C + head projections), 1 = Pooling (means of C)
     float* Cbuf;                               // ragged: pair b holds C (n2 x n1), row-major
     float* H1; float* H2;                      // [N x H] tanh outputs
     float* al1; float* al2;                    // [N] attention weights
@@ -187,6 +188,25 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
         }
     }
     __syncthreads();
+    if (a.mode == 1) {
+        // PoolingFineCoattention (PoolingFineCoattention.py:40-51): the atom scores are the means of the energy
+        // over the OTHER side's padded positions: e1[j] = sum_i w2_i C[i,j] / A2, e2[i] = sum_j w1_j C[i,j] / A1
+        if (tid < CO_MAXN) {
+            const int j = tid;
+            if (j < n1) {
+                float s = 0.f, A2 = 0.f;
+                for (int i = 0; i < n2; ++i) { s += L.w2s[i] * L.Cs[i * ldc + j]; A2 += L.w2s[i]; }
+                L.s1[j] = s / A2;
+            }
+        } else {
+            const int i = tid - CO_MAXN;
+            if (i < n2) {
+                float s = 0.f, A1 = 0.f;
+                for (int j = 0; j < n1; ++j) { s += L.w1s[j] * L.Cs[i * ldc + j]; A1 += L.w1s[j]; }
+                L.s2[i] = s / A1;
+            }
+        }
+    } else {
     co_stats(L, n1, n2, ldc);
     __syncthreads();
 
@@ -232,6 +252,7 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
             L.s2[i] = s;
         }
     }
+    }   // mode
     __syncthreads();
 
     // ---- atom softmax (default axis=1 = atoms, :364-366), wave 0: side 1, wave 1: side 2 ----
@@ -350,6 +371,18 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         for (int k = lane; k < n; k += 64) dt[k] = al[k] * (ww[k] * dt[k] - ww[k] * tsum);     // = ds_k
     }
     __syncthreads();
+    if (a.mode == 1) {
+        // Pooling: the scores are weighted means of C, so dC[i,j] = w2_i/A2 * ds1[j] + w1_j/A1 * ds2[i]
+        float A1 = 0.f, A2 = 0.f;
+        for (int j = 0; j < n1; ++j) A1 += L.w1s[j];
+        for (int i = 0; i < n2; ++i) A2 += L.w2s[i];
+        for (int idx = tid; idx < n2 * n1; idx += 256) {
+            const int i = idx / n1, j = idx % n1;
+            const float dc = L.w2s[i] / A2 * L.dots1[j] + L.w1s[j] / A1 * L.dots2[i];
+            L.dSs[i * ldc + j] = dc * bmp_dact(a.act, L.Cs[i * ldc + j]);
+        }
+        if (tid < 2 * H) a.dpart[(size_t)b * (2 * H + 1) + tid] = 0.f;
+    } else {
     // dHpre[k,h] = ds_k * wa[h] * (1 - H^2) ; per-pair partial of dwa[h] = sum_k ds_k H[k,h]
     for (int idx = tid; idx < (n1 + n2) * H; idx += 256) {
         const int row = idx / H, h = idx % H;
@@ -491,6 +524,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
             L.dSs[i * ldc + j] = dc * bmp_dact(a.act, L.Cs[i * ldc + j]);
         }
     }
+    }   // mode
     __syncthreads();
     // dv1[j] = sum_i dS[i,j] ; dv2[i] = sum_j dS[i,j] ; dc = sum_i dv2[i]
     if (tid < CO_MAXN) {
@@ -563,7 +597,7 @@ extern "C" int bmp_coattn_zcols(int o, int H) { return (o + H + 1 + 7) & ~7; }
 
 // Forward.  WbT [d x d] = W (bilinear form, [p][q]) so that Q2 = X2 . W^T uses it K-major as [q][p]:
 // pass WbT[q*d + p] = W[p][q].  ZW1T/ZW2T [d x ZC] K-major columns [Wj^T | Wl_k^T | V_k | 0]; zb [ZC] = [bj | 0].
-extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act,
+extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act, int mode,
                                   const float* w1, const int* r1, const int* n1, const float* w2, const int* r2,
                                   const int* n2, const long long* coff, int B, const int* order, int n32, int n64, int n96,
                                   int n128, const float* WbT,
@@ -591,7 +625,7 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
-    a.d = d; a.o = o; a.H = H; a.act = act; a.order = order;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode; a.order = order;
     a.Cbuf = Cbuf; a.H1 = H1; a.H2 = H2; a.al1 = al1; a.al2 = al2; a.out1 = out1; a.out2 = out2;
     // one launch per size class: LDS (and so the workgroups per CU) follows the pairs' actual sizes
     const int cnt[4] = {n32, n64, n96, n128};
@@ -630,7 +664,7 @@ extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d
 // Outputs: dX1, dX2 (written), dWbT [d x d], dZW1T/dZW2T [d x ZC], dzb [ZC] (sum of both sides),
 // dwa [2H + 1] = dwa1 | dwa2 | dc.
 extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
-                                  int n_tiles2, int d, int o, int H, int act, const float* w1, const int* r1,
+                                  int n_tiles2, int d, int o, int H, int act, int mode, const float* w1, const int* r1,
                                   const int* n1, const float* w2, const int* r2, const int* n2, const long long* coff,
                                   int B, const int* order, int n32, int n64, int n96, int n128, const float* Wb,
                                   const float* ZW1, const float* ZW2, const float* wa1,
@@ -658,7 +692,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2;
-    a.d = d; a.o = o; a.H = H; a.act = act; a.order = order;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode; a.order = order;
     a.Cbuf = const_cast<float*>(Cbuf); a.H1 = const_cast<float*>(H1); a.H2 = const_cast<float*>(H2);
     a.al1 = const_cast<float*>(al1); a.al2 = const_cast<float*>(al2);
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;

@@ -1,1 +1,1 @@
-from bmp.coattention import NieFineCoattention, VQAParallelCoattention  # noqa: F401  (models/coattention/__init__.py)
+from bmp.coattention import NieFineCoattention, VQAParallelCoattention, PoolingFineCoattention  # noqa: F401  (models/coattention/__init__.py)

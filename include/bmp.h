@@ -123,7 +123,7 @@ int bmp_linear_wgrad(const float* X, int ldx, const float* dY, int ldy, int N, i
  * counts (sum = B): one launch per class, LDS sized by the class.
  * Saves Q2 [N2 x d], Z1/Z2 [N x ZC], Cbuf (pair b at coff[b]: n2 x n1), H1/H2 [N x H], al1/al2 [N]. */
 int bmp_coattn_zcols(int o, int H);
-int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act,
+int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act, int mode,
                        const float* w1, const int* r1, const int* n1, const float* w2, const int* r2, const int* n2,
                        const long long* coff, int B, const int* order, int n32, int n64, int n96, int n128,
                        const float* WbT, const float* ZW1T, const float* ZW2T,
@@ -132,7 +132,7 @@ int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_til
                        bmp_stream_t stream);
 size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B);
 int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
-                       int n_tiles2, int d, int o, int H, int act, const float* w1, const int* r1, const int* n1,
+                       int n_tiles2, int d, int o, int H, int act, int mode, const float* w1, const int* r1, const int* n1,
                        const float* w2, const int* r2, const int* n2, const long long* coff, int B, const int* order,
                        int n32, int n64, int n96, int n128, const float* Wb, const float* ZW1, const float* ZW2, const float* wa1, const float* wa2,
                        const float* Q2, const float* Z1, const float* Z2, const float* Cbuf, const float* H1,

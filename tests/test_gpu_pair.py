@@ -137,3 +137,29 @@ def test_pair_no_attention_form(pairs):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("d,act", [(16, "tanh"), (64, "tanh")])
+def test_pooling_coattention_pair(pairs, d, act):
+    """PoolingFineCoattention (PoolingFineCoattention.py:31-57) through the pair predictor vs the dense oracle."""
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict, grad_dict
+    store, i1, i2, pb = pairs
+    pbd = to_dev(pb)
+    p = O.make_pair_params(31, hidden_dim=d, out_dim=d, n_layers=2, attn="pool", dtype=torch.float64)
+    p = {k: v.requires_grad_() for k, v in p.items()}
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn="pool")
+    c = torch.randn(y.shape, dtype=torch.float64)
+    (y * c).sum().backward()
+    model = build_pair_predictor(hidden_dim=d, out_dim=d, n_layers=2, attn="pool").to(dev())
+    load_param_dict(model, p)
+    yd = model(pbd)
+    close(yd, y, "logits"); close(model.g1, g1, "g1"); close(model.g2, g2, "g2")
+    (yd * c.float().to(dev())).sum().backward()
+    for name, gr in grad_dict(model).items():
+        ref = p[name].grad
+        if ref is None:
+            assert name.startswith(("graph_conv/i_layers", "graph_conv/j_layers")), name
+            continue
+        close(gr, ref, f"grad {name}")
