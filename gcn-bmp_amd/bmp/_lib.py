@@ -41,6 +41,14 @@ SIGNATURES = {
     "bmp_linear_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P]),
     "bmp_wgrad_ws_floats_c": (_Z, [_I, _I, _I]),
     "bmp_linear_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "bmp_segpool_fwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P]),
+    "bmp_segpool_bwd": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "bmp_segsoftmax_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "bmp_segsoftmax_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "bmp_rowbcast_fwd": (_I, [_P, _I, _P, _I, _P, _P]),
+    "bmp_rowbcast_bwd": (_I, [_P, _I, _P, _P, _I, _P, _P]),
+    "bmp_rowdot_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
+    "bmp_rowdot_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "bmp_coattn_zcols": (_I, [_I, _I]),
     "bmp_coattn_nie_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 17 + [_P]),
     "bmp_coattn_nie_bwd_ws_floats": (_Z, [_I] * 6),

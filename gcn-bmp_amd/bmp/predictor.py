@@ -88,6 +88,18 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
     elif attn == "pool":
         from .coattention import PoolingFineCoattention
         a = PoolingFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim)       # train_binary.py:210-212
+    elif attn == "parallel":
+        from .coarse import ParallelCoattention
+        a = ParallelCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=1, activation="tanh")   # train_binary.py:200-204
+    elif attn == "alternating":
+        from .coarse import AlternatingCoattention
+        a = AlternatingCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, weight_tying=True)
+    elif attn == "global":
+        from .coarse import GlobalCoattention
+        a = GlobalCoattention(hidden_dim=hidden_dim, out_dim=out_dim)
+    elif attn == "neural":
+        from .coarse import NeuralCoattention
+        a = NeuralCoattention(hidden_dim=hidden_dim, out_dim=out_dim, activation="tanh")
     elif attn is not None:
         raise ValueError('[ERROR] Invalid Co-Attention Method.')
     return GraphConvPredictorForPair(enc, a, MLP(class_num, mlp_hidden, in_dim=2 * out_dim))

@@ -113,6 +113,29 @@ size_t bmp_wgrad_ws_floats_c(int N, int K, int Nn);
 int bmp_linear_wgrad(const float* X, int ldx, const float* dY, int ldy, int N, int K, int Nn, float* dWT, float* db,
                      float* ws, size_t ws_floats, bmp_stream_t stream);
 
+/* Per-molecule segment operators -- the atom x molecule-vector arithmetic of the coarse co-attention family:
+ * ParallelCoattention parallel_coattention.py:34-84, AlternatingCoattention alternating_coattention.py:36-86,
+ * GlobalCoattention global_coattention.py:27-73, NeuralCoattention neural_coattention.py:27-71.
+ *   segpool   : out[m,c] = sum_rows w * A[r, c|0] * Y[r,c]            (ca = 1: per-atom scalar weight; ca = o: gate)
+ *   segsoftmax: alpha[r] = softmax over the molecule's atoms of s[r] (multiplicities in the denominator)
+ *   rowbcast  : out[r,:] = q[row_mol[r],:]  (tile the other molecule's vector over the atoms); bwd = per-molecule sum
+ *   rowdot    : s[r] = x[r,:] . u[row_mol[r],:] + s0[row_mol[r]]      (Bilinear / matmul of atom and molecule vector) */
+int bmp_segpool_fwd(const float* A, int ca, const float* Y, int o, const float* w, const int* mol_row0,
+                    const int* mol_nrows, int n_mols, float* out, bmp_stream_t stream);
+int bmp_segpool_bwd(const float* dout, const float* A, int ca, const float* Y, int o, const float* w, const int* mol_row0,
+                    const int* mol_nrows, int n_mols, int N, float* dA, float* dY, bmp_stream_t stream);
+int bmp_segsoftmax_fwd(const float* s, const float* w, const int* mol_row0, const int* mol_nrows, int n_mols, int N,
+                       float* alpha, bmp_stream_t stream);
+int bmp_segsoftmax_bwd(const float* dalpha, const float* alpha, const float* w, const int* mol_row0, const int* mol_nrows,
+                       int n_mols, int N, float* ds, bmp_stream_t stream);
+int bmp_rowbcast_fwd(const float* q, int c, const int* row_mol, int N, float* out, bmp_stream_t stream);
+int bmp_rowbcast_bwd(const float* d, int c, const int* mol_row0, const int* mol_nrows, int n_mols, float* dq,
+                     bmp_stream_t stream);
+int bmp_rowdot_fwd(const float* x, int d, const float* u, const float* s0, const int* row_mol, int N, float* s,
+                   bmp_stream_t stream);
+int bmp_rowdot_bwd(const float* ds, const float* x, int d, const float* u, const int* row_mol, const int* mol_row0,
+                   const int* mol_nrows, int n_mols, int N, float* dx, float* du, float* ds0, bmp_stream_t stream);
+
 /* Fine-grained co-attention -- NieFineCoattention.__call__ + compute_attention
  * models/coattention/nie_coattention.py:335-396 (VQAParallelCoattention
  * vqa_parallel_coattention.py:42-102 is the same computation).  Pair b couples rows

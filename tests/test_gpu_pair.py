@@ -163,3 +163,31 @@ def test_pooling_coattention_pair(pairs, d, act):
             assert name.startswith(("graph_conv/i_layers", "graph_conv/j_layers")), name
             continue
         close(gr, ref, f"grad {name}")
+
+
+@pytest.mark.parametrize("attn", ["parallel", "alternating", "global", "neural"])
+@pytest.mark.parametrize("joint", [True, False])
+def test_coarse_coattention_pair(pairs, attn, joint):
+    """Coarse (atom x molecule-vector) co-attention family through the pair predictor vs the dense oracle,
+    on one two-sided packed batch (joint) and in the reference's four-dense-array call form."""
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict, grad_dict
+    store, i1, i2, pb = pairs
+    d = 16
+    p = O.make_pair_params(41, hidden_dim=d, out_dim=d, n_layers=2, attn=attn, dtype=torch.float64)
+    p = {k: v.requires_grad_() for k, v in p.items()}
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn=attn)
+    c = torch.randn(y.shape, dtype=torch.float64)
+    (y * c).sum().backward()
+    model = build_pair_predictor(hidden_dim=d, out_dim=d, n_layers=2, attn=attn).to(dev())
+    load_param_dict(model, p)
+    yd = model(to_dev(pb)) if joint else model(T(a1), T(j1), T(a2), T(j2))
+    close(model.g1, g1, "g1"); close(model.g2, g2, "g2"); close(yd, y, "logits")
+    (yd * c.float().to(dev())).sum().backward()
+    for name, gr in grad_dict(model).items():
+        ref = p[name].grad
+        if ref is None:
+            assert float(gr.abs().max()) == 0.0, name
+            continue
+        close(gr, ref, f"grad {name}")
