@@ -190,4 +190,7 @@ def test_coarse_coattention_pair(pairs, attn, joint):
         if ref is None:
             assert float(gr.abs().max()) == 0.0, name
             continue
-        close(gr, ref, f"grad {name}")
+        # a bias added right before a softmax has an analytically zero gradient (shift invariance):
+        # compare it on the scale of the weight gradient of the same layer
+        floor = p["attn/energy_layers_2/0/W"].grad.abs().max().item() if name == "attn/energy_layers_2/0/b" else 1e-6
+        close(gr, ref, f"grad {name}", floor=floor)
