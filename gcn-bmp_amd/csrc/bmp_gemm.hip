@@ -99,22 +99,40 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
             }
             __syncthreads();
             const float* wp = Wt + (size_t)(k0 + 4 * hi) * ldw;
+            // operands of k-step s+1 (weights from L2, row fragments from LDS) are requested before the MFMAs
+            // of step s issue; scheduling barriers keep the compiler from sinking the loads behind them
+            f32x4 a0[RB], a1[RB];
+            float b0[CBW][4], b1[CBW][4];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a0[rb] = *(const f32x4*)(&lds[((wr * RB + rb) * 32 + l31) * BMP_LDS_LD + 4 * hi]);
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b0[cb][t] = wp[(size_t)t * ldw + colc[cb]];
             for (int kk = 0; kk < kc; kk += 8) {
-                f32x4 av[RB];
+                if (kk + 8 < kc) {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-                    av[rb] = *(const f32x4*)(&lds[((wr * RB + rb) * 32 + l31) * BMP_LDS_LD + kk + 4 * hi]);
-                float bv[CBW][4];
+                    for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
-                for (int cb = 0; cb < CBW; ++cb)
+                        for (int t = 0; t < 4; ++t) b1[cb][t] = wp[(size_t)(kk + 8 + t) * ldw + colc[cb]];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) bv[cb][t] = wp[(size_t)(kk + t) * ldw + colc[cb]];
+                    for (int rb = 0; rb < RB; ++rb)
+                        a1[rb] = *(const f32x4*)(&lds[((wr * RB + rb) * 32 + l31) * BMP_LDS_LD + kk + 8 + 4 * hi]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = bmp_mfma(av[rb][t], bv[cb][t], acc[rb][cb]);
+                        for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = bmp_mfma(a0[rb][t], b0[cb][t], acc[rb][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a0[rb] = a1[rb];
+#pragma unroll
+                for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b0[cb][t] = b1[cb][t];
             }
         }
     }
