@@ -196,10 +196,21 @@ def main():
             # algorithmic flops count real atoms only
             alg_flops = pc["flops"] * real_frac
             achieved = alg_flops / (pc["ms"] * 1e-3) / 1e12
-            names = {1: "k_rowgemm (fp32 MFMA row GEMM)", 2: "k_wgrad (fp32 MFMA weight-gradient GEMM)",
+            names = {1: "k_rowgemm (fp32 MFMA row GEMM)", 2: "k_wgrad_lds (fp32 MFMA weight-gradient GEMM)",
                      5: "k_ggnn_step_fwd", 6: "k_ggnn_step_bwd"}
+            # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 --pmc
+            # passes of this same command, committed under profiles/), not measurable from inside this process
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.json")))
+                key = {5: "k_ggnn_step_fwd<128, false>", 6: "k_ggnn_step_bwd<128, false>", 2: "k_wgrad_lds<false>",
+                       1: "k_rowgemm<1, 4, 1, 0>"}.get(cls)
+                if key in pmc:
+                    traffic = round((pmc[key]["FETCH_SIZE_per_launch"] + pmc[key]["WRITE_SIZE_per_launch"]) * 1024)
+            except (OSError, ValueError):
+                pass
             roof = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=None, kernel=names.get(cls, str(cls)),
+                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=names.get(cls, str(cls)),
                         launches_per_step=pc["launches"], avg_launch_us=round(1e3 * pc["ms"] / pc["launches"], 2),
                         alg_gflop_per_launch=round(alg_flops / pc["launches"] / 1e9, 4),
                         class_ms_per_step={str(k): round(v["ms"], 3) for k, v in per_class.items()},
