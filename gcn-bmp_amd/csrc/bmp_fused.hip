@@ -11,6 +11,7 @@
 //   wave (wr, wc) owns rows [wr*RB*32, +RB*32) x cols [wc*32, +32) of every [128 x D] result,
 //   D = 128: 2 x 4 waves, RB = 2;  D = 64: 4 x 2 waves, RB = 1.
 //   dense work: v_mfma_f32_32x32x2_f32 (exact f32); K order per lane: four consecutive k per 16-B read.
+#include <stdlib.h>
 #include <string.h>
 #include "bmp_kernels.h"
 
@@ -20,6 +21,7 @@ struct StepArgs {
     // graph
     const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
     int first;
+    int dbg;   // TEMP diagnostic
     // forward
     const float* h;                 // [N x D] step input
     const float* WT;                // [4D x D]  message weights, K-major (row e*D + k, col c)
@@ -44,7 +46,8 @@ struct StepArgs {
 // starting rows, so the 256 CUs do not all request the same L2 lines at the same moment.
 template <int NB, int RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot) {
+                                         const int (&ldw)[NB], int K, int rot, int dbg = 0) {
+    if (dbg & 8) return;
     // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
     // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
     // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
@@ -96,7 +99,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 // arrays, or the copy of the tile's entries staged in LDS -- see stage_csr).
 template <int D>
 __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_tile, int LD, const int* ptr, const int* col,
-                                            const float* val, int row0, int e, float* wsum) {
+                                            const float* val, int row0, int e, float* wsum, int* tmask) {
     constexpr int F = D / 16;                 // float4 per thread
     const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
     f32x4 acc[F];
@@ -107,6 +110,7 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
     const int e0 = ptr[row], e1 = ptr[row + 1];
     for (int ed = e0; ed < e1; ++ed) {
         const int cv = col[ed];
+        *tmask |= 1 << (cv & 3);
         if ((cv & 3) == e) {
             const float v = val[ed];
             const float* s = src_tile + ((cv >> 2) - row0) * LD + q * (D / 4);
@@ -135,8 +139,29 @@ __device__ __forceinline__ bool stage_csr(const int* ptr, const int* col, const 
     for (int i = threadIdx.x; i < ne; i += 512) { ecol[i] = col[ebase + i]; evalv[i] = val[ebase + i]; }
     return true;
 }
-#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp) \
-                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp))
+#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp, &tmask) \
+                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp, &tmask))
+
+// ---- half-tile groups --------------------------------------------------------------------------------------
+// Waves 0-3 own rows [0, 64) of the tile and waves 4-7 rows [64, 128) in every phase (gather rows, MFMA A rows,
+// epilogue rows), so between the few points where a phase reads the WHOLE tile the two halves are independent.
+// They synchronise separately, on a monotonic LDS counter per group (gfx950 has one hardware barrier per
+// workgroup), and group 0 runs at a higher wave priority: with one wave of each group on every SIMD, group 0
+// takes the matrix pipe whenever it wants it and group 1 fills the gaps group 0 leaves while it gathers, runs
+// epilogues or waits for memory.  In lockstep (one barrier for all eight waves) both waves of a SIMD sit in their
+// non-MFMA phases at the same time and the matrix pipe idles for a third of the tile's life.
+struct GrpSync {
+    int* ctr;       // LDS, zeroed before the first workgroup barrier
+    int target;
+};
+__device__ __forceinline__ void grp_sync(GrpSync& g) {
+    g.target += 4;                                   // four waves per group
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(g.ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(g.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g.target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#define FZ_NSYNC 8          // ints of LDS: ctr[2] at +0,+1 ; type masks [2] at +2,+3
 
 // Accumulator-layout access to a row-major [rows x LDC] f32 array through a buffer resource: all 16*RB
 // positions of a wave share ONE 32-bit voffset VGPR (the lane's (row, col) byte offset); the per-register
@@ -164,9 +189,39 @@ __device__ __forceinline__ void acc_st(const AccBuf& b, int rb, int reg, float v
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.rs, b.vo, so, 0);
 }
 
+// Row-major access to one 64-row half of a tile, 16 bytes per lane: slot v of thread tg (0..255) is the
+// float4 at (half row v * (1024 / D) + tg / (D/4), float4 column tg % (D/4)); the per-slot row offset is a
+// compile-time soffset, so all slots of one array share one voffset VGPR (see AccBuf).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int D, int LDP>
+__device__ __forceinline__ AccBuf rm_buf(const float* base, int tile_row0, int grp, int tg) {
+    AccBuf b;
+    b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)tile_row0 * LDP), 0, 0x7FFFFFFF, 0x00020000);
+    b.vo = ((grp * 64 + tg / (D / 4)) * LDP + 4 * (tg % (D / 4))) * 4;
+    return b;
+}
+template <int D, int LDP>
+__device__ __forceinline__ f32x4 rm_ld(const AccBuf& b, int v, int coff = 0) {
+    const int so = (v * (1024 / D) * LDP + coff) * 4;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.vo, so, 0));
+}
+template <int D, int LDP>
+__device__ __forceinline__ void rm_st(const AccBuf& b, int v, f32x4 x, int coff = 0) {
+    // The slot offset rides in the voffset here, not in an SGPR soffset: a 16-byte buffer store with a register
+    // soffset still reads its data VGPRs when the next instruction issues, hipcc (ROCm 7.2) schedules a VALU
+    // write of those VGPRs right behind it without the wait state, and the stored row arrives corrupted
+    // (seen on gfx950: two of the four dwords replaced by the following v_pk_mul's result).
+    const int so = (v * (1024 / D) * LDP + coff) * 4;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), b.rs, b.vo + so, 0, 0);
+}
+
+#define ACC_LD(T, b, rb, reg, ...) ((a.dbg & 2) ? 0.5f : acc_ld<T>(b, rb, reg, ##__VA_ARGS__))
+#define ACC_ST(T, b, rb, reg, v, ...) do { if (!(a.dbg & 1)) acc_st<T>(b, rb, reg, v, ##__VA_ARGS__); } while (0)
 #define FZ_FOR_ACC _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)
 
-template <int D, bool FIRST>
+#define FZ_GSYNC() do { if (STAG) grp_sync(gs); else __syncthreads(); } while (0)
+
+template <int D, bool FIRST, bool STAG>
 __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -177,8 +232,14 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     int* rptr = (int*)(wds + FZ_R * 4);      // [132]       tile-relative CSR row pointers
     int* ecol = rptr + 132;                  // [FZ_ECAP]
     float* evalv = (float*)(ecol + FZ_ECAP); // [FZ_ECAP]
+    int* sy = (int*)(evalv + FZ_ECAP);       // [FZ_NSYNC]  group counters, bond-type masks
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int grp = w >> 2;                  // half of the tile this wave works on in every phase
+    GrpSync gs{sy + grp, 0};
+    int tmask = 0;
+    if (tid < FZ_NSYNC) sy[tid] = 0;
+    if (STAG && grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
     const int row0 = blockIdx.x * FZ_R;
@@ -193,7 +254,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 #define LOFF(rb, reg) (((rb) * 32 + ((reg) & 3) + 8 * ((reg) >> 2)) * LD)
 
     // ---- h tile -> LDS ----
-    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+    if (!(a.dbg & 2)) for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
         *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
     }
@@ -205,15 +266,22 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     zero_acc(acc_m[0]);
     for (int e = 0; e < 4; ++e) {
         float wd;
-        const bool mine = FZ_GATHER(Hs, As, e, &wd);
+        bool mine = false; wd = 0.f; if (!(a.dbg & 4)) mine = FZ_GATHER(Hs, As, e, &wd); else tmask = 15;
         if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
-        const int any = __syncthreads_or(mine ? 1 : 0);
+        int any;
+        if (STAG) {     // bond types present in this half of the tile: known after the first pass (it walks every entry)
+            if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            grp_sync(gs);
+            any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
+        } else {
+            any = __syncthreads_or(mine ? 1 : 0);
+        }
         if (any) {
             const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
             const int ldw[1] = {D};
-            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot);
+            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot, a.dbg);
         }
-        __syncthreads();
+        FZ_GSYNC();
     }
     // m -> LDS (A operand of the gates) and HBM (saved for the backward)
     {
@@ -226,10 +294,10 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
             const float v = acc_m[0][rb][reg] + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
             Al[LOFF(rb, reg)] = v;
-            acc_st<D>(mo, rb, reg, v);
+            ACC_ST(D, mo, rb, reg, v);
         }
     }
-    __syncthreads();
+    FZ_GSYNC();
 
     // ---- gates: [r | z | c~] = [h, m] . AT   (chainer StatefulGRU) ----
     f32x16 acc_g[3][RB];
@@ -244,15 +312,15 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const int ldw2[2] = {3 * D, 3 * D};
             const float* const Bh[2] = {base_h + 4 * D, base_h + 8 * D};
             const float* const Bm[2] = {base_m + 4 * D, base_m + 8 * D};
-            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D, rot);
-            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D, rot);
+            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D, rot, a.dbg);
+            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D, rot, a.dbg);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) { acc_g[1][rb] = g2[0][rb]; acc_g[2][rb] = g2[1][rb]; }
         } else {
             const float* const Bh[3] = {base_h, base_h + 4 * D, base_h + 8 * D};
             const float* const Bm[3] = {base_m, base_m + 4 * D, base_m + 8 * D};
-            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D, rot);
-            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D, rot);
+            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D, rot, a.dbg);
+            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D, rot, a.dbg);
         }
     }
     const float br = a.b[col], bz = a.b[D + col], bcn = a.b[2 * D + col];
@@ -261,24 +329,24 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         FZ_FOR_ACC {
             const float zv = bmp_sigmoid(acc_g[1][rb][reg] + bz);
             acc_g[1][rb][reg] = zv;
-            acc_st<2 * D>(rzo, rb, reg, zv, D);
+            ACC_ST(2 * D, rzo, rb, reg, zv, D);
             if (!FIRST) {
                 const float rv = bmp_sigmoid(acc_g[0][rb][reg] + br);
                 acc_g[0][rb][reg] = rv;
-                acc_st<2 * D>(rzo, rb, reg, rv, 0);
+                ACC_ST(2 * D, rzo, rb, reg, rv, 0);
             }
         }
     }
     if (!FIRST) {
-        __syncthreads();                     // every wave is done reading M
+        FZ_GSYNC();                          // every wave of this half is done reading M
         FZ_FOR_ACC { Al[LOFF(rb, reg)] = acc_g[0][rb][reg] * Hl[LOFF(rb, reg)]; }      // r * h
-        __syncthreads();
+        FZ_GSYNC();
         f32x16 gc[1][RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
         const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
         const int ldu[1] = {D};
-        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot);
+        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot, a.dbg);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
     }
@@ -291,8 +359,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const float zv = acc_g[1][rb][reg];
             float hn = zv * cv;
             if (!FIRST) hn += (1.f - zv) * Hl[LOFF(rb, reg)];
-            acc_st<D>(co, rb, reg, cv);
-            acc_st<D>(ho, rb, reg, hn);
+            ACC_ST(D, co, rb, reg, cv);
+            ACC_ST(D, ho, rb, reg, hn);
         }
     }
 }
@@ -300,18 +368,32 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 // Backward of one step for one tile: all of the backward-data path (gate derivatives, the three
 // transposed gate GEMMs, the message-linear transpose and the transposed neighbour gather), and the
 // per-row pre-activation gradients [G | da] the weight-gradient GEMMs consume.
-template <int D, bool FIRST>
+//
+// All HBM traffic is row-major 16-byte accesses (a wave instruction moves 1 KiB of one or two rows): the
+// elementwise gate derivatives are computed in that layout straight from the loads and land in LDS as the
+// MFMA A operands; what the MFMAs produce in accumulator layout (d(r*h), dm, dh) crosses to row-major
+// through the LDS tile it has to visit anyway.  (Accumulator-layout dword loads/stores of the same arrays
+// cost 64 + 30 us of a 287 us launch.)
+template <int D, bool FIRST, bool STAG>
 __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    constexpr int F4 = D / 4;                // float4 per row
+    constexpr int NV = D / 16;               // float4 per thread of a 64-row half (256 threads)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Xs = lds;                         // [128 x LD]  da_c -> da_r -> da_z -> dm
-    float* Ys = lds + FZ_R * LD;             // [128 x LD]  G_e (transposed gather of dm)
+    float* Xs = lds;                         // [128 x LD]  da_c -> d(r*h) -> da_r -> dm
+    float* Ys = lds + FZ_R * LD;             // [128 x LD]  da_z -> G_e (transposed gather of dm) -> dh
     int* rptr = (int*)(Ys + FZ_R * LD + FZ_R * 4);
     int* ecol = rptr + 132;
     float* evalv = (float*)(ecol + FZ_ECAP);
+    int* sy = (int*)(evalv + FZ_ECAP);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int grp = w >> 2;
+    GrpSync gs{sy + grp, 0};
+    int tmask = 0;
+    if (tid < FZ_NSYNC) sy[tid] = 0;
+    if (STAG && grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
     const int row0 = blockIdx.x * FZ_R;
@@ -322,36 +404,56 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     const float* Xw = Xs + (wrow0 + l31) * LD + 4 * hi;
     const float* Yw = Ys + (wrow0 + l31) * LD + 4 * hi;
     float* Xl = Xs + lrow * LD + col;
+    float* Yl = Ys + lrow * LD + col;
     constexpr bool first = FIRST;
+    // row-major view of this half: float4 slot v of this thread = (tile row rm_r(v), float4 column rm_c(v))
+    const int tg = tid & 255;
+#define RM_ROW(v) (grp * 64 + ((v) * 256 + tg) / F4)
+#define RM_C4(v) (((v) * 256 + tg) % F4)
+#define RM_LDS(T, v) (*(f32x4*)((T) + RM_ROW(v) * LD + 4 * RM_C4(v)))
+    const AccBuf b_g = rm_buf<D, D>(a.dhout, row0, grp, tg), b_c = rm_buf<D, D>(a.c, row0, grp, tg);
+    const AccBuf b_h = rm_buf<D, D>(a.h, row0, grp, tg), b_rz = rm_buf<D, 2 * D>(a.rz, row0, grp, tg);
+    const AccBuf b_o = rm_buf<D, 7 * D>(a.gda, row0, grp, tg), b_dh = rm_buf<D, D>(a.dh, row0, grp, tg);
 
     const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);     // visible after the first barrier
-    const AccBuf gi = acc_buf<D>(a.dhout, row0, lrow, col);
-    const AccBuf ci = acc_buf<D>(a.c, row0, lrow, col);
-    const AccBuf hin = acc_buf<D>(a.h, row0, lrow, col);
-    const AccBuf rzi = acc_buf<2 * D>(a.rz, row0, lrow, col);
-    const AccBuf go = acc_buf<7 * D>(a.gda, row0, lrow, col);
 
-    // ---- X = da_c = dh' * z * (1 - c^2);  dh accumulator starts at dh' * (1 - z) (0 on the first call) ----
+    // ---- da_c = dh' z (1 - c^2) -> X ; da_z = dh' (c - h) z (1 - z) -> Y ; ex = dh' (1 - z): the direct part of dh ----
+    f32x4 ex[NV];
+    {
+        const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+        f32x4 g4[NV], z4[NV], c4[NV], h4[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            g4[v] = rm_ld<D, D>(b_g, v);
+            z4[v] = rm_ld<D, 2 * D>(b_rz, v, D);
+            c4[v] = rm_ld<D, D>(b_c, v);
+            if (!first) h4[v] = rm_ld<D, D>(b_h, v);
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 gz = g4[v] * z4[v];
+            const f32x4 dac = gz * (one - c4[v] * c4[v]);
+            f32x4 dz = gz * (one - z4[v]);
+            if (first) { dz *= c4[v]; ex[v] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            else { dz *= (c4[v] - h4[v]); ex[v] = g4[v] - gz; }
+            RM_LDS(Xs, v) = dac;
+            RM_LDS(Ys, v) = dz;
+            rm_st<D, 7 * D>(b_o, v, dac, 6 * D);
+            rm_st<D, 7 * D>(b_o, v, dz, 5 * D);
+            if (first) rm_st<D, 7 * D>(b_o, v, (f32x4){0.f, 0.f, 0.f, 0.f}, 4 * D);       // da_r = 0
+        }
+    }
+    __syncthreads();                         // whole workgroup: the staged CSR and the counters are visible
+
     f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
     zero_acc(acc_x[0]); zero_acc(acc_x[1]);
-    FZ_FOR_ACC {
-        const float g = acc_ld<D>(gi, rb, reg);
-        const float z = acc_ld<2 * D>(rzi, rb, reg, D);
-        const float cv = acc_ld<D>(ci, rb, reg);
-        const float dac = g * z * (1.f - cv * cv);
-        if (!first) acc_x[0][rb][reg] = g * (1.f - z);
-        Xl[LOFF(rb, reg)] = dac;
-        acc_st<7 * D>(go, rb, reg, dac, 6 * D);
-    }
-    __syncthreads();
-
     const float* const Ac_h = a.A + (size_t)(2 * D + 4 * hi) * 2 * D + 4 * col;
     const float* const Az_h = a.A + (size_t)(D + 4 * hi) * 2 * D + 4 * col;
     const float* const Ar_h = a.A + (size_t)(4 * hi) * 2 * D + 4 * col;
     const int ld2[2] = {2 * D, 2 * D};
     {   // [dh | dm] += da_c . A_c
         const float* const Bc[2] = {Ac_h, Ac_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot);
+        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot, a.dbg);
     }
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
@@ -359,46 +461,38 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         {
             const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
-            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot);
+            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot, a.dbg);
         }
-        __syncthreads();                     // all waves done with da_c in X
-        // da_r = d(r*h) * h * r * (1-r) -> X ; dh += d(r*h) * r
-        FZ_FOR_ACC {
-            const float rv = acc_ld<2 * D>(rzi, rb, reg, 0);
-            const float hv = acc_ld<D>(hin, rb, reg);
-            const float drh = acc_d[0][rb][reg];
-            const float dar = drh * hv * rv * (1.f - rv);
-            acc_x[0][rb][reg] += drh * rv;
-            Xl[LOFF(rb, reg)] = dar;
-            acc_st<7 * D>(go, rb, reg, dar, 4 * D);
+        FZ_GSYNC();                          // all waves of this half done with da_c in X
+        FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_d[0][rb][reg]; }
+        f32x4 r4[NV], h4[NV];                // in flight across the group barrier
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { r4[v] = rm_ld<D, 2 * D>(b_rz, v); h4[v] = rm_ld<D, D>(b_h, v); }
+        FZ_GSYNC();
+        // da_r = d(r*h) h r (1-r) -> X (in place) ; ex += d(r*h) r
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 drh = RM_LDS(Xs, v);
+            const f32x4 dr = drh * r4[v];
+            const f32x4 dar = dr * h4[v] * ((f32x4){1.f, 1.f, 1.f, 1.f} - r4[v]);
+            ex[v] += dr;
+            RM_LDS(Xs, v) = dar;
+            rm_st<D, 7 * D>(b_o, v, dar, 4 * D);
         }
-        __syncthreads();
-        {   // X = da_r
+        FZ_GSYNC();
+        {
             const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
-            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot);
+            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot, a.dbg);
         }
     }
-    __syncthreads();
-    // da_z = dh' * (c - h) * z * (1-z) -> X   (first call: h term absent)
-    FZ_FOR_ACC {
-        const float g = acc_ld<D>(gi, rb, reg);
-        const float z = acc_ld<2 * D>(rzi, rb, reg, D);
-        const float cv = acc_ld<D>(ci, rb, reg);
-        const float hv = first ? 0.f : acc_ld<D>(hin, rb, reg);
-        const float dz = g * (cv - hv) * z * (1.f - z);
-        Xl[LOFF(rb, reg)] = dz;
-        acc_st<7 * D>(go, rb, reg, dz, 5 * D);
-        if (first) acc_st<7 * D>(go, rb, reg, 0.f, 4 * D);          // da_r = 0
-    }
-    __syncthreads();
-    {
+    {   // da_z has been waiting in Y since the prologue
         const float* const Bz[2] = {Az_h, Az_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Xw, LD, Bz, ld2, D, rot);
+        tile_mma<2, RB>(acc_x, Yw, LD, Bz, ld2, D, rot, a.dbg);
     }
-    __syncthreads();                         // all waves done with X
+    FZ_GSYNC();                              // all waves of this half done with X and Y
     // ---- X <- dm ----
     FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_x[1][rb][reg]; }
-    __syncthreads();
+    __syncthreads();                         // whole workgroup: the transposed gather reads dm of every row of the tile
 
     // ---- message backward: G_e = gather^T_e(dm) ; dh += G_e . W_e^T ----
     f32x16 acc_h[1][RB];
@@ -406,7 +500,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     for (int rb = 0; rb < RB; ++rb) acc_h[0][rb] = acc_x[0][rb];
     for (int e = 0; e < 4; ++e) {
         float wd;
-        const bool mine = FZ_GATHER(Xs, Ys, e, &wd);
+        bool mine = false; wd = 0.f; if (!(a.dbg & 4)) mine = FZ_GATHER(Xs, Ys, e, &wd); else tmask = 15;
         {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + row * LD + q * (D / 4);
@@ -414,41 +508,58 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #pragma unroll
             for (int f = 0; f < D / 16; ++f) *(f32x4*)(o + 4 * f) = *(const f32x4*)(s + 4 * f);
         }
-        const int any = __syncthreads_or(mine ? 1 : 0);
+        int any;
+        if (STAG) {
+            if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            grp_sync(gs);
+            any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
+        } else {
+            any = __syncthreads_or(mine ? 1 : 0);
+        }
         if (any) {
             const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
             const int ldw[1] = {4 * D};
-            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot);
+            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, a.dbg);
         }
-        __syncthreads();
+        FZ_GSYNC();
     }
-    {
-        const AccBuf dho = acc_buf<D>(a.dh, row0, lrow, col);
-        FZ_FOR_ACC { acc_st<D>(dho, rb, reg, acc_h[0][rb][reg]); }
-    }
+    // ---- dh = (MFMA part, via Y) + ex ----
+    FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
+    FZ_GSYNC();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v) + ex[v]);
+#undef RM_ROW
+#undef RM_C4
+#undef RM_LDS
 }
 #undef LOFF
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 4 + 132 + 2 * FZ_ECAP) * sizeof(float); }
+static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 4 + 132 + 2 * FZ_ECAP + FZ_NSYNC) * sizeof(float); }
 
 extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 
-template <int D, bool FIRST>
-static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
-    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST> : (const void*)k_ggnn_step_fwd<D, FIRST>;
+template <int D, bool FIRST, bool STAG>
+static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
+    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, STAG> : (const void*)k_ggnn_step_fwd<D, FIRST, STAG>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
     if (e != hipSuccess) return (int)e;
     const double rows = (double)n_tiles * FZ_R;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
                       4.0 * rows * D * (bwd ? 13.0 : 6.0), st);
-    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST, STAG>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, STAG>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
+}
+
+template <int D, bool FIRST>
+static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
+    static const int lockstep = getenv("BMP_STEP_LOCKSTEP") ? atoi(getenv("BMP_STEP_LOCKSTEP")) : 0;   // A/B switch (tools/)
+    return lockstep ? fz_launch3<D, FIRST, false>(bwd, a, n_tiles, st) : fz_launch3<D, FIRST, true>(bwd, a, n_tiles, st);
 }
 
 template <int D>
@@ -463,7 +574,7 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, 
                                  const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.dbg = getenv("BMP_DBG") ? atoi(getenv("BMP_DBG")) : 0;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
@@ -475,36 +586,60 @@ extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float
                                  const float* Wnat, const float* A, const float* Uc, float* dh, float* gda, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first;
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.dbg = getenv("BMP_DBG") ? atoi(getenv("BMP_DBG")) : 0;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
 
-extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
-    return bmp_wgrad_ws_floats(N, d, 7 * d);
+static void fz_wgrad_desc(WGMulti& w, const float* const* h, const float* const* m, const float* const* rz,
+                          const float* const* gda, int n_steps, int N, int d, int first, float* o1, float* o2, float* dUcT,
+                          float* cs, int accumulate) {
+    memset(&w, 0, sizeof(w));
+    w.nprob = first ? 2 : 3; w.nsteps = n_steps; w.N = N; w.accumulate = accumulate;
+    WGMultiProb& g1 = w.p[0]; WGMultiProb& g2 = w.p[1]; WGMultiProb& g3 = w.p[2];
+    for (int s = 0; s < n_steps; ++s) {
+        g1.X[s] = h ? h[s] : nullptr; g1.dY[s] = gda ? gda[s] : nullptr;
+        g2.X[s] = m ? m[s] : nullptr; g2.dY[s] = gda ? gda[s] + 4 * d : nullptr;
+        g3.X[s] = rz ? rz[s] : nullptr; g3.X2[s] = h ? h[s] : nullptr; g3.dY[s] = gda ? gda[s] + 6 * d : nullptr;
+    }
+    g1.ldx = d; g1.ldy = 7 * d; g1.K = d; g1.Nn = 7 * d; g1.out = o1; g1.ldo = 7 * d; g1.cs = cs;      // + column sums of gda
+    g2.ldx = d; g2.ldy = 7 * d; g2.K = d; g2.Nn = 3 * d; g2.out = o2; g2.ldo = 3 * d;
+    g3.ldx = 2 * d; g3.ldx2 = d; g3.ldy = 7 * d; g3.K = d; g3.Nn = d; g3.out = dUcT; g3.ldo = d;
 }
 
-// Weight gradients of one step (reduction over all N = n_tiles*128 rows):
-//   o1 [d x 7d]  = h^T . gda        cols [0,4d): dWT as [k][e*d + c];  cols [4d,7d): dAT rows 0..d-1
-//   o2 [d x 3d]  = m^T . da         = dAT rows d..2d-1
-//   dUcT [d x d] = (r*h)^T . da_c   (zeros when first)
+extern "C" size_t bmp_ggnn_steps_wgrad_ws_floats(int N, int d, int n_steps) {
+    WGMulti w;
+    fz_wgrad_desc(w, nullptr, nullptr, nullptr, nullptr, n_steps, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0);
+    return bmp_wgrad_multi_ws_floats(w);
+}
+extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) { return bmp_ggnn_steps_wgrad_ws_floats(N, d, 1); }
+
+// Weight gradients of n_steps propagation steps that share their weights (reduction over all N = n_tiles*128
+// rows of every step), ONE batched GEMM launch + one slab reduction:
+//   o1 [d x 7d]  = sum_s h_s^T . gda_s     cols [0,4d): dWT as [k][e*d + c];  cols [4d,7d): dAT rows 0..d-1
+//   o2 [d x 3d]  = sum_s m_s^T . da_s      = dAT rows d..2d-1
+//   dUcT [d x d] = sum_s (r*h)_s^T . da_c  (zeros when first)
 //   cs [7d]      = column sums of gda: [dbE as e*d + c | db]
-// accumulate != 0 adds into the outputs (weight tying: one set of buffers for all steps).
-extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
-                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
-                                   size_t ws_floats, hipStream_t st) {
-    BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
-    int rc;
-    WGArgs g1{h, nullptr, d, 0, gda, 7 * d, d, 7 * d, N, o1, 7 * d, accumulate, cs};     // + column sums of gda
-    if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
-    WGArgs g2{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, 3 * d, N, o2, 3 * d, accumulate};
-    if ((rc = bmp_launch_wgrad(g2, ws, st))) return rc;
-    if (!first) {
-        WGArgs g3{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
-        if ((rc = bmp_launch_wgrad(g3, ws, st))) return rc;
-    } else if (!accumulate) {
+// h, m, rz, gda: host arrays of n_steps (<= 8) device pointers.  accumulate != 0 adds into the outputs.
+extern "C" int bmp_ggnn_steps_wgrad(const float* const* h, const float* const* m, const float* const* rz,
+                                    const float* const* gda, int n_steps, int N, int d, int first, float* o1, float* o2,
+                                    float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
+    BMP_REQUIRE(h && m && rz && gda && n_steps >= 1 && n_steps <= 8 && N > 0 && d > 0 && (d & 3) == 0);
+    BMP_REQUIRE(ws_floats >= bmp_ggnn_steps_wgrad_ws_floats(N, d, n_steps));
+    WGMulti w;
+    fz_wgrad_desc(w, h, m, rz, gda, n_steps, N, d, first, o1, o2, dUcT, cs, accumulate);
+    int rc = bmp_launch_wgrad_multi(w, ws, st);
+    if (rc) return rc;
+    if (first && !accumulate) {
         hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+// Single-step form.
+extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
+                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
+                                   size_t ws_floats, hipStream_t st) {
+    return bmp_ggnn_steps_wgrad(&h, &m, &rz, &gda, 1, N, d, first, o1, o2, dUcT, cs, accumulate, ws, ws_floats, st);
 }
