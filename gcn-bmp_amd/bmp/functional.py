@@ -7,8 +7,6 @@ in bmp/ggnn.py etc., so parameter gradients come back in the reference layout.
 """
 from __future__ import annotations
 
-import ctypes
-
 import torch
 from torch.autograd import Function
 
@@ -219,29 +217,27 @@ class GGNNStepFn(Function):
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(A), ptr(Uc), ptr(dh), ptr(gda),
                                   stream()), "bmp_ggnn_step_bwd")
-        # Steps that share BOTH weight sets (tied layers) hand their saved arrays to the last of them to run, which
-        # reduces all of them in ONE batched weight-gradient launch (bmp_ggnn_steps_wgrad).
+        # Steps that share BOTH weight sets (tied layers) accumulate their weight gradients in one set of
+        # buffers inside the kernels; only the last of them to run hands the sums to autograd.
         grp = ("g", WT.data_ptr(), AT.data_ptr())
-        n_shared = cache.get(("n",) + grp[1:], 1) if cache is not None else 1
-        steps = [(h, m, rz, gda)]
-        if n_shared > 1:
-            pend = cache.setdefault(grp, [])
-            pend.append(steps[0])
-            if len(pend) < n_shared:
+        st = None
+        if cache is not None and cache.get(("n",) + grp[1:], 1) > 1:
+            st = cache.setdefault(grp, dict(seen=0, buf=None))
+        if st is None or st["buf"] is None:
+            o1, o2, dUcT, cs = f(d, 7 * d), f(d, 3 * d), f(d, d), f(7 * d)
+            if st is not None:
+                st["buf"] = (o1, o2, dUcT, cs)
+        else:
+            o1, o2, dUcT, cs = st["buf"]
+        acc = 1 if (st is not None and st["seen"] > 0) else 0
+        nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
+        ws = _ws(nws, dev)
+        check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(o1), ptr(o2), ptr(dUcT), ptr(cs),
+                                    acc, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+        if st is not None:
+            st["seen"] += 1
+            if st["seen"] < cache[("n",) + grp[1:]]:
                 return dh, None, None, None, None, None, None, None, None
-            steps = pend
-            cache[grp] = []
-        o1, o2, dUcT, cs = f(d, 7 * d), f(d, 3 * d), f(d, d), f(7 * d)
-        ns = len(steps)
-        acc = 0
-        for lo in range(0, ns, 8):                       # the C ABI takes up to 8 steps per call
-            part = steps[lo:lo + 8]
-            arrs = [(ctypes.c_void_p * len(part))(*[t[k].data_ptr() for t in part]) for k in range(4)]
-            nws = L.bmp_ggnn_steps_wgrad_ws_floats(N, d, len(part))
-            ws = _ws(nws, dev)
-            check(L.bmp_ggnn_steps_wgrad(arrs[0], arrs[1], arrs[2], arrs[3], len(part), N, d, first, ptr(o1), ptr(o2),
-                                         ptr(dUcT), ptr(cs), acc, ptr(ws), nws, stream()), "bmp_ggnn_steps_wgrad")
-            acc = 1
         dWT = o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)      # [k][e*d+c] -> [e*d+k][c]
         dbE = cs[:4 * d].reshape(4, d)
         dAT = torch.cat((o1[:, 4 * d:], o2), dim=0)

@@ -21,7 +21,6 @@ struct StepArgs {
     // graph
     const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
     int first;
-    int dbg;   // TEMP diagnostic
     // forward
     const float* h;                 // [N x D] step input
     const float* WT;                // [4D x D]  message weights, K-major (row e*D + k, col c)
@@ -46,8 +45,7 @@ struct StepArgs {
 // starting rows, so the 256 CUs do not all request the same L2 lines at the same moment.
 template <int NB, int RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot, int dbg = 0) {
-    if (dbg & 8) return;
+                                         const int (&ldw)[NB], int K, int rot) {
     // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
     // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
     // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
@@ -215,13 +213,11 @@ __device__ __forceinline__ void rm_st(const AccBuf& b, int v, f32x4 x, int coff 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), b.rs, b.vo + so, 0, 0);
 }
 
-#define ACC_LD(T, b, rb, reg, ...) ((a.dbg & 2) ? 0.5f : acc_ld<T>(b, rb, reg, ##__VA_ARGS__))
-#define ACC_ST(T, b, rb, reg, v, ...) do { if (!(a.dbg & 1)) acc_st<T>(b, rb, reg, v, ##__VA_ARGS__); } while (0)
 #define FZ_FOR_ACC _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)
 
-#define FZ_GSYNC() do { if (STAG) grp_sync(gs); else __syncthreads(); } while (0)
+#define FZ_GSYNC() grp_sync(gs)
 
-template <int D, bool FIRST, bool STAG>
+template <int D, bool FIRST>
 __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -239,7 +235,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     GrpSync gs{sy + grp, 0};
     int tmask = 0;
     if (tid < FZ_NSYNC) sy[tid] = 0;
-    if (STAG && grp == 0) __builtin_amdgcn_s_setprio(2);
+    if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
     const int row0 = blockIdx.x * FZ_R;
@@ -254,7 +250,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 #define LOFF(rb, reg) (((rb) * 32 + ((reg) & 3) + 8 * ((reg) >> 2)) * LD)
 
     // ---- h tile -> LDS ----
-    if (!(a.dbg & 2)) for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
         *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
     }
@@ -266,20 +262,16 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     zero_acc(acc_m[0]);
     for (int e = 0; e < 4; ++e) {
         float wd;
-        bool mine = false; wd = 0.f; if (!(a.dbg & 4)) mine = FZ_GATHER(Hs, As, e, &wd); else tmask = 15;
+        FZ_GATHER(Hs, As, e, &wd);
         if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
-        int any;
-        if (STAG) {     // bond types present in this half of the tile: known after the first pass (it walks every entry)
-            if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            grp_sync(gs);
-            any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        } else {
-            any = __syncthreads_or(mine ? 1 : 0);
-        }
+        // bond types present in this half of the tile: known after the first pass (it walks every entry)
+        if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        grp_sync(gs);
+        const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
         if (any) {
             const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
             const int ldw[1] = {D};
-            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot, a.dbg);
+            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot);
         }
         FZ_GSYNC();
     }
@@ -294,7 +286,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
             const float v = acc_m[0][rb][reg] + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
             Al[LOFF(rb, reg)] = v;
-            ACC_ST(D, mo, rb, reg, v);
+            acc_st<D>(mo, rb, reg, v);
         }
     }
     FZ_GSYNC();
@@ -312,15 +304,15 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const int ldw2[2] = {3 * D, 3 * D};
             const float* const Bh[2] = {base_h + 4 * D, base_h + 8 * D};
             const float* const Bm[2] = {base_m + 4 * D, base_m + 8 * D};
-            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D, rot, a.dbg);
-            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D, rot, a.dbg);
+            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D, rot);
+            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D, rot);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) { acc_g[1][rb] = g2[0][rb]; acc_g[2][rb] = g2[1][rb]; }
         } else {
             const float* const Bh[3] = {base_h, base_h + 4 * D, base_h + 8 * D};
             const float* const Bm[3] = {base_m, base_m + 4 * D, base_m + 8 * D};
-            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D, rot, a.dbg);
-            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D, rot, a.dbg);
+            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D, rot);
+            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D, rot);
         }
     }
     const float br = a.b[col], bz = a.b[D + col], bcn = a.b[2 * D + col];
@@ -329,11 +321,11 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         FZ_FOR_ACC {
             const float zv = bmp_sigmoid(acc_g[1][rb][reg] + bz);
             acc_g[1][rb][reg] = zv;
-            ACC_ST(2 * D, rzo, rb, reg, zv, D);
+            acc_st<2 * D>(rzo, rb, reg, zv, D);
             if (!FIRST) {
                 const float rv = bmp_sigmoid(acc_g[0][rb][reg] + br);
                 acc_g[0][rb][reg] = rv;
-                ACC_ST(2 * D, rzo, rb, reg, rv, 0);
+                acc_st<2 * D>(rzo, rb, reg, rv, 0);
             }
         }
     }
@@ -346,7 +338,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
         const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
         const int ldu[1] = {D};
-        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot, a.dbg);
+        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
     }
@@ -359,8 +351,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const float zv = acc_g[1][rb][reg];
             float hn = zv * cv;
             if (!FIRST) hn += (1.f - zv) * Hl[LOFF(rb, reg)];
-            ACC_ST(D, co, rb, reg, cv);
-            ACC_ST(D, ho, rb, reg, hn);
+            acc_st<D>(co, rb, reg, cv);
+            acc_st<D>(ho, rb, reg, hn);
         }
     }
 }
@@ -374,7 +366,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 // MFMA A operands; what the MFMAs produce in accumulator layout (d(r*h), dm, dh) crosses to row-major
 // through the LDS tile it has to visit anyway.  (Accumulator-layout dword loads/stores of the same arrays
 // cost 64 + 30 us of a 287 us launch.)
-template <int D, bool FIRST, bool STAG>
+template <int D, bool FIRST>
 __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -393,7 +385,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     GrpSync gs{sy + grp, 0};
     int tmask = 0;
     if (tid < FZ_NSYNC) sy[tid] = 0;
-    if (STAG && grp == 0) __builtin_amdgcn_s_setprio(2);
+    if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
     const int row0 = blockIdx.x * FZ_R;
@@ -453,7 +445,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     const int ld2[2] = {2 * D, 2 * D};
     {   // [dh | dm] += da_c . A_c
         const float* const Bc[2] = {Ac_h, Ac_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot, a.dbg);
+        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot);
     }
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
@@ -461,7 +453,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         {
             const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
-            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot, a.dbg);
+            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot);
         }
         FZ_GSYNC();                          // all waves of this half done with da_c in X
         FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_d[0][rb][reg]; }
@@ -482,12 +474,12 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         FZ_GSYNC();
         {
             const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
-            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot, a.dbg);
+            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot);
         }
     }
     {   // da_z has been waiting in Y since the prologue
         const float* const Bz[2] = {Az_h, Az_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Yw, LD, Bz, ld2, D, rot, a.dbg);
+        tile_mma<2, RB>(acc_x, Yw, LD, Bz, ld2, D, rot);
     }
     FZ_GSYNC();                              // all waves of this half done with X and Y
     // ---- X <- dm ----
@@ -500,7 +492,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     for (int rb = 0; rb < RB; ++rb) acc_h[0][rb] = acc_x[0][rb];
     for (int e = 0; e < 4; ++e) {
         float wd;
-        bool mine = false; wd = 0.f; if (!(a.dbg & 4)) mine = FZ_GATHER(Xs, Ys, e, &wd); else tmask = 15;
+        FZ_GATHER(Xs, Ys, e, &wd);
         {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + row * LD + q * (D / 4);
@@ -508,18 +500,13 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #pragma unroll
             for (int f = 0; f < D / 16; ++f) *(f32x4*)(o + 4 * f) = *(const f32x4*)(s + 4 * f);
         }
-        int any;
-        if (STAG) {
-            if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            grp_sync(gs);
-            any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        } else {
-            any = __syncthreads_or(mine ? 1 : 0);
-        }
+        if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        grp_sync(gs);
+        const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
         if (any) {
             const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
             const int ldw[1] = {4 * D};
-            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, a.dbg);
+            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot);
         }
         FZ_GSYNC();
     }
@@ -541,25 +528,19 @@ static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 
 
 extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 
-template <int D, bool FIRST, bool STAG>
-static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
-    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, STAG> : (const void*)k_ggnn_step_fwd<D, FIRST, STAG>;
+template <int D, bool FIRST>
+static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
+    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST> : (const void*)k_ggnn_step_fwd<D, FIRST>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
     if (e != hipSuccess) return (int)e;
     const double rows = (double)n_tiles * FZ_R;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
                       4.0 * rows * D * (bwd ? 13.0 : 6.0), st);
-    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST, STAG>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, STAG>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
-}
-
-template <int D, bool FIRST>
-static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
-    static const int lockstep = getenv("BMP_STEP_LOCKSTEP") ? atoi(getenv("BMP_STEP_LOCKSTEP")) : 0;   // A/B switch (tools/)
-    return lockstep ? fz_launch3<D, FIRST, false>(bwd, a, n_tiles, st) : fz_launch3<D, FIRST, true>(bwd, a, n_tiles, st);
 }
 
 template <int D>
@@ -574,7 +555,7 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, 
                                  const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.dbg = getenv("BMP_DBG") ? atoi(getenv("BMP_DBG")) : 0;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
@@ -586,60 +567,36 @@ extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float
                                  const float* Wnat, const float* A, const float* Uc, float* dh, float* gda, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.dbg = getenv("BMP_DBG") ? atoi(getenv("BMP_DBG")) : 0;
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
 
-static void fz_wgrad_desc(WGMulti& w, const float* const* h, const float* const* m, const float* const* rz,
-                          const float* const* gda, int n_steps, int N, int d, int first, float* o1, float* o2, float* dUcT,
-                          float* cs, int accumulate) {
-    memset(&w, 0, sizeof(w));
-    w.nprob = first ? 2 : 3; w.nsteps = n_steps; w.N = N; w.accumulate = accumulate;
-    WGMultiProb& g1 = w.p[0]; WGMultiProb& g2 = w.p[1]; WGMultiProb& g3 = w.p[2];
-    for (int s = 0; s < n_steps; ++s) {
-        g1.X[s] = h ? h[s] : nullptr; g1.dY[s] = gda ? gda[s] : nullptr;
-        g2.X[s] = m ? m[s] : nullptr; g2.dY[s] = gda ? gda[s] + 4 * d : nullptr;
-        g3.X[s] = rz ? rz[s] : nullptr; g3.X2[s] = h ? h[s] : nullptr; g3.dY[s] = gda ? gda[s] + 6 * d : nullptr;
-    }
-    g1.ldx = d; g1.ldy = 7 * d; g1.K = d; g1.Nn = 7 * d; g1.out = o1; g1.ldo = 7 * d; g1.cs = cs;      // + column sums of gda
-    g2.ldx = d; g2.ldy = 7 * d; g2.K = d; g2.Nn = 3 * d; g2.out = o2; g2.ldo = 3 * d;
-    g3.ldx = 2 * d; g3.ldx2 = d; g3.ldy = 7 * d; g3.K = d; g3.Nn = d; g3.out = dUcT; g3.ldo = d;
+extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
+    return bmp_wgrad_ws_floats(N, d, 7 * d);
 }
 
-extern "C" size_t bmp_ggnn_steps_wgrad_ws_floats(int N, int d, int n_steps) {
-    WGMulti w;
-    fz_wgrad_desc(w, nullptr, nullptr, nullptr, nullptr, n_steps, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0);
-    return bmp_wgrad_multi_ws_floats(w);
-}
-extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) { return bmp_ggnn_steps_wgrad_ws_floats(N, d, 1); }
-
-// Weight gradients of n_steps propagation steps that share their weights (reduction over all N = n_tiles*128
-// rows of every step), ONE batched GEMM launch + one slab reduction:
-//   o1 [d x 7d]  = sum_s h_s^T . gda_s     cols [0,4d): dWT as [k][e*d + c];  cols [4d,7d): dAT rows 0..d-1
-//   o2 [d x 3d]  = sum_s m_s^T . da_s      = dAT rows d..2d-1
-//   dUcT [d x d] = sum_s (r*h)_s^T . da_c  (zeros when first)
+// Weight gradients of one step (reduction over all N = n_tiles*128 rows):
+//   o1 [d x 7d]  = h^T . gda        cols [0,4d): dWT as [k][e*d + c];  cols [4d,7d): dAT rows 0..d-1
+//   o2 [d x 3d]  = m^T . da         = dAT rows d..2d-1
+//   dUcT [d x d] = (r*h)^T . da_c   (zeros when first)
 //   cs [7d]      = column sums of gda: [dbE as e*d + c | db]
-// h, m, rz, gda: host arrays of n_steps (<= 8) device pointers.  accumulate != 0 adds into the outputs.
-extern "C" int bmp_ggnn_steps_wgrad(const float* const* h, const float* const* m, const float* const* rz,
-                                    const float* const* gda, int n_steps, int N, int d, int first, float* o1, float* o2,
-                                    float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
-    BMP_REQUIRE(h && m && rz && gda && n_steps >= 1 && n_steps <= 8 && N > 0 && d > 0 && (d & 3) == 0);
-    BMP_REQUIRE(ws_floats >= bmp_ggnn_steps_wgrad_ws_floats(N, d, n_steps));
-    WGMulti w;
-    fz_wgrad_desc(w, h, m, rz, gda, n_steps, N, d, first, o1, o2, dUcT, cs, accumulate);
-    int rc = bmp_launch_wgrad_multi(w, ws, st);
-    if (rc) return rc;
-    if (first && !accumulate) {
+// accumulate != 0 adds into the outputs (weight tying: one set of buffers for all steps).
+extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
+                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
+                                   size_t ws_floats, hipStream_t st) {
+    BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
+    int rc;
+    WGArgs g1{h, nullptr, d, 0, gda, 7 * d, d, 7 * d, N, o1, 7 * d, accumulate, cs};     // + column sums of gda
+    if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
+    WGArgs g2{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, 3 * d, N, o2, 3 * d, accumulate};
+    if ((rc = bmp_launch_wgrad(g2, ws, st))) return rc;
+    if (!first) {
+        WGArgs g3{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
+        if ((rc = bmp_launch_wgrad(g3, ws, st))) return rc;
+    } else if (!accumulate) {
         hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
     return 0;
-}
-
-// Single-step form.
-extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
-                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
-                                   size_t ws_floats, hipStream_t st) {
-    return bmp_ggnn_steps_wgrad(&h, &m, &rz, &gda, 1, N, d, first, o1, o2, dUcT, cs, accumulate, ws, ws_floats, st);
 }

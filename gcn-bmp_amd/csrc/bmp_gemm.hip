@@ -1,6 +1,5 @@
 // fp32-MFMA GEMM building blocks for gfx950: the row GEMM (atom-row tiles x weights) and the
 // weight-gradient GEMM (reduction over atom rows).  See bmp_kernels.h for the contracts.
-#include <string.h>
 #include "bmp_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -401,242 +400,6 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Batched weight-gradient GEMM: up to 3 problems (X_p^T . dY_p over the same N rows) x up to 8 row sets
-// ("steps": the tied propagation steps of one encoder call, every one with its own X / dY arrays) in ONE
-// launch, so that the whole batch fills the chip once: one work item = (row split, 128x128 output tile).
-//   * work items with the same row split read the same X rows (and overlapping dY column ranges): they are
-//     dealt to the same XCD (blocks b and b+8 share one), so those re-reads are hits in that XCD's L2;
-//   * a split never crosses a step; S_total = splits_per_step * n_steps slabs per problem, reduced in a
-//     fixed order by k_reduce_multi (bitwise reproducible).
-// Same staging as k_wgrad_lds: 32-row stages through double-buffered LDS, 2 workgroups per CU.
-// ---------------------------------------------------------------------------------------------
-#define WGM_MAXS 8
-struct WGMProb {
-    const float* X[WGM_MAXS]; const float* X2[WGM_MAXS]; const float* dY[WGM_MAXS];
-    int ldx, ldx2, ldy, K, Nn, want_cs;
-    int tile0, tiles_j;              // this problem's tiles are [tile0, tile0 + tiles_i * tiles_j), j fastest
-    long long slab_off;              // floats
-};
-struct WGMArgs {
-    WGMProb p[3];
-    int nprob, ntiles, N, sps, rps, S;
-    float* slab;
-};
-
-__global__ __launch_bounds__(256) void k_wgrad_multi(WGMArgs a) {
-    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
-    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int s = (q / a.ntiles) * 8 + xcd, t = q % a.ntiles;
-    if (s >= a.S) return;
-    int pi = 0;
-    if (a.nprob > 1 && t >= a.p[1].tile0) pi = 1;
-    if (a.nprob > 2 && t >= a.p[2].tile0) pi = 2;
-    const WGMProb& P = a.p[pi];
-    const int tl = t - P.tile0;
-    const int i_tile = (tl / P.tiles_j) * 128, j_tile = (tl % P.tiles_j) * 128;
-    const int step = s / a.sps, chunk = s % a.sps;
-    const float* __restrict__ X = P.X[step];
-    const float* __restrict__ X2 = P.X2[step];
-    const float* __restrict__ dY = P.dY[step];
-    const int r_begin = chunk * a.rps;
-    const int r_end = (r_begin + a.rps) < a.N ? (r_begin + a.rps) : a.N;
-    const int nst = r_end > r_begin ? (r_end - r_begin) >> 5 : 0;
-    const int c4 = tid & 31, rr = tid >> 5;
-    const int colx = i_tile + 4 * c4, coly = j_tile + 4 * c4;
-    const bool okx = colx < P.K, oky = coly < P.Nn;
-    const bool do_cs = P.want_cs && i_tile == 0;
-    const int Krows = P.K + (P.want_cs ? 1 : 0);
-    const int ldx = P.ldx, ldx2 = P.ldx2, ldy = P.ldy;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-    f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 xr[4], yr[4];
-    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#define WG_LOAD(st)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-        const size_t row = (size_t)(r_begin + (st) * 32 + rr + 8 * i);                               \
-        xr[i] = okx ? *(const f32x4*)(X + row * ldx + colx) : zero4;                                  \
-        if (X2 && okx) xr[i] *= *(const f32x4*)(X2 + row * ldx2 + colx);                             \
-        yr[i] = oky ? *(const f32x4*)(dY + row * ldy + coly) : zero4;                                 \
-    }
-#define WG_STORE(buf)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-        *(f32x4*)(&XS[buf][rr + 8 * i][4 * c4]) = xr[i];                                             \
-        *(f32x4*)(&YS[buf][rr + 8 * i][4 * c4]) = yr[i];                                             \
-        csum += yr[i];                                                                               \
-    }
-
-    if (nst > 0) {
-        WG_LOAD(0)
-        WG_STORE(0)
-    }
-    __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nst) { WG_LOAD(st + 1) }
-        float av[2][2][4], bv[2][2][4];
-#define WG_FRAG(slot, k0)                                                                              \
-    _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                                 \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
-            av[slot][m][t4] = XS[buf][(k0) + 4 * hi + t4][wm * 64 + m * 32 + l31];                     \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                  \
-            bv[slot][n][t4] = YS[buf][(k0) + 4 * hi + t4][wn * 64 + n * 32 + l31];                     \
-    }
-        WG_FRAG(0, 0)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < 4) { WG_FRAG(cur ^ 1, (ks + 1) * 8) }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t4], bv[cur][n][t4], acc[m][n]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#undef WG_FRAG
-        if (st + 1 < nst) { WG_STORE(buf ^ 1) }
-        __syncthreads();
-    }
-#undef WG_LOAD
-#undef WG_STORE
-
-    float* slab = a.slab + P.slab_off + (size_t)s * Krows * P.Nn;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int j = j_tile + wn * 64 + n * 32 + l31;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int i = i_tile + wm * 64 + m * 32 + bmp_acc_row(reg, lane);
-                if (i < P.K && j < P.Nn) slab[(size_t)i * P.Nn + j] = acc[m][n][reg];
-            }
-        }
-    if (do_cs) {        // column sums of this split's dY rows: reduce the 8 row groups through LDS
-        f32x4* red = (f32x4*)&XS[0][0][0];
-        red[rr * 32 + c4] = csum;
-        __syncthreads();
-        if (rr == 0 && oky) {
-            f32x4 t4 = red[c4];
-#pragma unroll
-            for (int g = 1; g < 8; ++g) t4 += red[g * 32 + c4];
-            *(f32x4*)(slab + (size_t)P.K * P.Nn + coly) = t4;
-        }
-    }
-}
-
-struct RMProb { long long slab_off; int Krows, Nn, ldo, cs_row; float* out; float* cs_out; };
-struct RMArgs { RMProb p[3]; const float* slab; int S, accumulate; };
-
-// out_p[i, j] (=|+=) sum_s slab_p[s][i][j] for every problem (blockIdx.y), fixed order
-__global__ __launch_bounds__(256) void k_reduce_multi(RMArgs a) {
-    __shared__ float red[4][64];
-    const RMProb& P = a.p[blockIdx.y];
-    const float* __restrict__ slab = a.slab + P.slab_off;
-    const size_t total = (size_t)P.Krows * P.Nn;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
-        const size_t idx = base + c;
-        float v = 0.f;
-        if (idx < total) {
-#pragma unroll 8
-            for (int s = g; s < a.S; s += 4) v += slab[(size_t)s * total + idx];
-        }
-        red[g][c] = v;
-        __syncthreads();
-        if (g == 0 && idx < total) {
-            v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-            const int i = (int)(idx / P.Nn), j = (int)(idx % P.Nn);
-            float* o = (i == P.cs_row) ? (P.cs_out + j) : (P.out + (size_t)i * P.ldo + j);
-            *o = a.accumulate ? (*o + v) : v;
-        }
-        __syncthreads();
-    }
-}
-
-static void wgrad_multi_plan(const WGMulti& m, int& ntiles, int& sps, int& rps, int& S) {
-    ntiles = 0;
-    for (int p = 0; p < m.nprob; ++p) ntiles += ((m.p[p].K + 127) / 128) * ((m.p[p].Nn + 127) / 128);
-    int want = 512 / (ntiles * m.nsteps);             // 2 workgroups per CU, everything in ONE round
-    if (want < 1) want = 1;
-    int max_s = m.N / 256;                            // at least 256 rows (8 stages) per split
-    if (max_s < 1) max_s = 1;
-    sps = want < max_s ? want : max_s;
-    rps = (m.N + sps - 1) / sps;
-    rps = (rps + 31) & ~31;
-    sps = (m.N + rps - 1) / rps;
-    S = sps * m.nsteps;
-}
-
-size_t bmp_wgrad_multi_ws_floats(const WGMulti& m) {
-    int ntiles, sps, rps, S;
-    wgrad_multi_plan(m, ntiles, sps, rps, S);
-    size_t per = 0;
-    for (int p = 0; p < m.nprob; ++p) per += (size_t)(m.p[p].K + (m.p[p].cs ? 1 : 0)) * m.p[p].Nn;
-    return per * S;
-}
-
-int bmp_launch_wgrad_multi(const WGMulti& m, float* ws, hipStream_t st) {
-    BMP_REQUIRE(m.nprob >= 1 && m.nprob <= 3 && m.nsteps >= 1 && m.nsteps <= WGM_MAXS && m.N > 0 && (m.N & 31) == 0 && ws);
-    WGMArgs a; memset(&a, 0, sizeof(a));
-    RMArgs r; memset(&r, 0, sizeof(r));
-    int ntiles, sps, rps, S;
-    wgrad_multi_plan(m, ntiles, sps, rps, S);
-    a.nprob = m.nprob; a.ntiles = ntiles; a.N = m.N; a.sps = sps; a.rps = rps; a.S = S; a.slab = ws;
-    r.slab = ws; r.S = S; r.accumulate = m.accumulate;
-    int tile0 = 0;
-    long long off = 0;
-    double flops = 0, bytes = 0;
-    size_t max_total = 0;
-    for (int p = 0; p < m.nprob; ++p) {
-        const WGMultiProb& q = m.p[p];
-        BMP_REQUIRE(q.K > 0 && q.Nn > 0 && (q.K & 3) == 0 && (q.Nn & 3) == 0 && (q.ldx & 3) == 0 && (q.ldy & 3) == 0 &&
-                    (q.ldx2 & 3) == 0);
-        WGMProb& P = a.p[p];
-        for (int s = 0; s < m.nsteps; ++s) {
-            BMP_REQUIRE(q.X[s] && q.dY[s] && ((uintptr_t)q.X[s] & 15) == 0 && ((uintptr_t)q.dY[s] & 15) == 0 &&
-                        ((uintptr_t)q.X2[s] & 15) == 0);
-            P.X[s] = q.X[s]; P.X2[s] = q.X2[s]; P.dY[s] = q.dY[s];
-        }
-        P.ldx = q.ldx; P.ldx2 = q.ldx2; P.ldy = q.ldy; P.K = q.K; P.Nn = q.Nn; P.want_cs = q.cs != nullptr;
-        P.tile0 = tile0; P.tiles_j = (q.Nn + 127) / 128;
-        P.slab_off = off;
-        const int Krows = q.K + (q.cs ? 1 : 0);
-        r.p[p] = RMProb{off, Krows, q.Nn, q.ldo, q.cs ? q.K : -1, q.out, q.cs};
-        tile0 += ((q.K + 127) / 128) * P.tiles_j;
-        off += (long long)S * Krows * q.Nn;
-        if ((size_t)Krows * q.Nn > max_total) max_total = (size_t)Krows * q.Nn;
-        flops += 2.0 * m.N * m.nsteps * (double)q.K * q.Nn;
-        bytes += 4.0 * m.N * m.nsteps * ((double)q.K + q.Nn);
-    }
-    const int groups = (S + 7) / 8;
-    {
-        BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st);
-        hipLaunchKernelGGL(k_wgrad_multi, dim3(8 * groups * ntiles), dim3(256), 0, st, a);
-    }
-    BMP_LAUNCH_CHECK();
-    int blocks = (int)((max_total + 63) / 64);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_reduce_multi, dim3(blocks, m.nprob), dim3(256), 0, st, r);
-    BMP_LAUNCH_CHECK();
-    return 0;
-}
-
 static void wgrad_plan(int N, int K, int Nn, int& mb, int& nb, int& S, int& rps) {
     mb = K > 32 ? 2 : 1;
     nb = Nn > 32 ? 2 : 1;
@@ -659,8 +422,8 @@ static bool wgrad_use_lds(const WGArgs& a) {
 
 static void wgrad_lds_plan(int N, int K, int Nn, int& S, int& rps) {
     const int tiles = ((K + 127) / 128) * ((Nn + 127) / 128);
-    int want = 512 / tiles;                           // 2 workgroups per CU and NO second round (7 tiles x 74 = 518 > 512
-    if (want < 1) want = 1;                           // slots made every launch wait for six stragglers)
+    int want = 512 / tiles;                           // 2 workgroups per CU and NO second round: 7 tiles x 74 splits = 518
+    if (want < 1) want = 1;                           // workgroups on 512 slots made a launch wait for six stragglers
     int max_s = N / 256;                              // at least 256 rows (8 stages) per split
     if (max_s < 1) max_s = 1;
     S = want < max_s ? want : max_s;

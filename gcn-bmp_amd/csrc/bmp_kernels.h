@@ -62,21 +62,6 @@ struct WGArgs {
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
 
-// Batched form: up to 3 problems x up to 8 row sets ("steps", each with its own X / X2 / dY arrays of N rows) in one
-// launch + one reduction; out_p (=|+=) sum over steps and rows.
-struct WGMultiProb {
-    const float* X[8]; const float* X2[8]; const float* dY[8];
-    int ldx, ldx2, ldy, K, Nn;
-    float* out; int ldo;
-    float* cs;                       // optional column sums of dY
-};
-struct WGMulti {
-    WGMultiProb p[3];
-    int nprob, nsteps, N, accumulate;
-};
-size_t bmp_wgrad_multi_ws_floats(const WGMulti& m);
-int bmp_launch_wgrad_multi(const WGMulti& m, float* ws, hipStream_t st);
-
 // column sums: out[n] (=|+=) sum_rows dY[row, n]
 size_t bmp_colsum_ws_floats(int N, int Nn);
 int bmp_launch_colsum(const float* dY, int ldy, int N, int Nn, float* out, int accumulate, float* ws, hipStream_t st);

@@ -92,12 +92,6 @@ size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
 int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first,
                         float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats,
                         bmp_stream_t stream);
-/* The same over n_steps (<= 8) propagation steps that share their weights (weight_tying, models/ggnn.py:220): h, m,
- * rz, gda are HOST arrays of n_steps device pointers; one batched GEMM launch + one reduction for all of them. */
-size_t bmp_ggnn_steps_wgrad_ws_floats(int N, int d, int n_steps);
-int bmp_ggnn_steps_wgrad(const float* const* h, const float* const* m, const float* const* rz, const float* const* gda,
-                         int n_steps, int N, int d, int first, float* o1, float* o2, float* dUcT, float* cs,
-                         int accumulate, float* ws, size_t ws_floats, bmp_stream_t stream);
 
 /* Gated-sum readout -- GGNN.readout models/ggnn.py:333-341 and GGNNReadout.__call__
  * models/readout/ggnn_readout.py:42-57.  g[mol] = sum_rows w * sigmoid(i(.)) * act_j(j(.)).

@@ -36,7 +36,7 @@ for _ in range(3):
     run()
 torch.cuda.synchronize()
 out = (ctypes.c_double * 3)()
-res = {"tiles": pb.n_tiles, "dbg": os.environ.get("BMP_DBG", "0"), "lockstep": os.environ.get("BMP_STEP_LOCKSTEP", "0")}
+res = {"tiles": pb.n_tiles, "d": d}
 for cls, name in ((5, "fwd"), (6, "bwd")):
     L.bmp_prof_start(cls)
     for _ in range(reps):
