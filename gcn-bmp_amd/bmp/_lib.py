@@ -7,14 +7,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_size_t, c_void_p
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbmp_hip.so")
 
-_P, _I, _Z = c_void_p, c_int, c_size_t
+_P, _I, _Z, _F = c_void_p, c_int, c_size_t, c_float
 
 # name -> (restype, argtypes); mirrors include/bmp.h declaration by declaration
 SIGNATURES = {
@@ -49,6 +49,8 @@ SIGNATURES = {
     "bmp_rowbcast_bwd": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "bmp_rowdot_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "bmp_rowdot_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bmp_gather_sum": (_I, [_P, _I, _P, _P, _I, _I, _P]),
+    "bmp_adam_step": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P]),
     "bmp_coattn_zcols": (_I, [_I, _I]),
     "bmp_coattn_nie_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 17 + [_P]),
     "bmp_coattn_nie_bwd_ws_floats": (_Z, [_I] * 6),

@@ -137,7 +137,86 @@ class NieCoattnFn(Function):
                 None, None, None)
 
 
-class NieFineCoattention(nn.Module):
+class PNieFn(Function):
+    """NieCoattnFn on prepared weights (bmp/plan.py).  W: WbT, ZW1T, ZW2T, zb, wa1, wa2, cbias, Wb, ZW1, ZW2;
+    G: dWbT, dZW1T, dZW2T, dzb, dwa."""
+
+    @staticmethod
+    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode):
+        L = _lib.lib()
+        dev = X1.device
+        B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
+        ZC = L.bmp_coattn_zcols(o, H)
+        X1 = X1.contiguous(); X2 = X2.contiguous()
+        N1, N2 = X1.shape[0], X2.shape[0]
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        Q2, Z1, Z2 = f(N2, d), f(N1, ZC), f(N2, ZC)
+        Cbuf = f(max(meta["ctotal"], 1))
+        H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)
+        out1, out2 = f(B, o), f(B, o)
+        check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
+                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order"]),
+                                   *meta["counts"], ptr(W["WbT"]), ptr(W["ZW1T"]), ptr(W["ZW2T"]), ptr(W["zb"]), ptr(W["wa1"]),
+                                   ptr(W["wa2"]), ptr(W["cbias"]), ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2),
+                                   ptr(al1), ptr(al2), ptr(out1), ptr(out2), stream()), "bmp_coattn_nie_fwd")
+        ctx.save_for_backward(X1, X2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
+        ctx.meta, ctx.dims, ctx.W, ctx.G = meta, (d, o, H, act, ZC, mode), W, G
+        return out1, out2
+
+    @staticmethod
+    def backward(ctx, dout1, dout2):
+        L = _lib.lib()
+        X1, X2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2 = ctx.saved_tensors
+        meta, W, G = ctx.meta, ctx.W, ctx.G
+        d, o, H, act, ZC, mode = ctx.dims
+        B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
+        dout1, dout2 = dout1.contiguous(), dout2.contiguous()
+        dX1, dX2 = torch.empty_like(X1), torch.empty_like(X2)
+        nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
+        ws = _ws(nws, X1.device)
+        check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1),
+                                   ptr(meta["r1"]), ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]),
+                                   ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], ptr(W["Wb"]), ptr(W["ZW1"]),
+                                   ptr(W["ZW2"]), ptr(W["wa1"]), ptr(W["wa2"]),
+                                   ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
+                                   ptr(dX2), ptr(G["dWbT"]), ptr(G["dZW1T"]), ptr(G["dZW2T"]), ptr(G["dzb"]), ptr(G["dwa"]),
+                                   ptr(ws), nws, stream()), "bmp_coattn_nie_bwd")
+        return dX1, dX2, None, None, None, None, None, None, None, None, None, None
+
+
+class _FinePlanMixin:
+    """Layout plan protocol (bmp/plan.py) of the fine co-attention family, on top of ``_kernel_weights()``."""
+
+    def plannable(self) -> bool:
+        return True
+
+    def primary_layouts(self):
+        names = ("WbT", "ZW1T", "ZW2T", "zb", "wa1", "wa2", "cbias")
+        return {k: v.contiguous() for k, v in zip(names, self._kernel_weights())}
+
+    def prepared_layouts(self):
+        p = self.primary_layouts()
+        p.update(Wb=p["WbT"].t().contiguous(), ZW1=p["ZW1T"].t().contiguous(), ZW2=p["ZW2T"].t().contiguous())
+        return p
+
+    def gk_spec(self):
+        d, o, H = self.hidden_dim, self.out_dim, self._heads()
+        ZC = _lib.lib().bmp_coattn_zcols(o, H)
+        return {"dWbT": (d, d), "dZW1T": (d, ZC), "dZW2T": (d, ZC), "dzb": (ZC,), "dwa": (2 * H + 1,)}
+
+    def primary_grads(self, gk):
+        H = self._heads()
+        return {"WbT": [gk["dWbT"]], "ZW1T": [gk["dZW1T"]], "ZW2T": [gk["dZW2T"]], "zb": [gk["dzb"]],
+                "wa1": [gk["dwa"][:H]], "wa2": [gk["dwa"][H:2 * H]], "cbias": [gk["dwa"][2 * H:]]}
+
+    def _forward_fast(self, atoms_1, atoms_2, fast, mode):
+        P, G, _state, _tape = fast
+        X1, X2, w1, w2, meta, _joint = pair_rows(atoms_1, atoms_2)
+        return PNieFn.apply(X1, X2, P, G, w1, w2, meta, self.hidden_dim, self.out_dim, self._heads(),
+                            ACT[self.activation], mode)
+
+
+class NieFineCoattention(_FinePlanMixin, nn.Module):
     """models/coattention/nie_coattention.py:312-396."""
 
     def __init__(self, hidden_dim, out_dim, head, activation="identity"):
@@ -159,21 +238,27 @@ class NieFineCoattention(nn.Module):
             raise ValueError(f"unsupported activation {activation!r}")
         self.activation = activation
 
+    def _heads(self) -> int:
+        return self.head
+
     def _kernel_weights(self):
         d, o, H = self.hidden_dim, self.out_dim, self.head
         ZC = _lib.lib().bmp_coattn_zcols(o, H)
         E = self.energy_layer
         dev = E.W.device
         WbT = E.W[:, :, 0].t()                                                  # [q][p] = W[p][q]
-        pad = torch.zeros(d, ZC - o - H - 1, device=dev)
+        pad = torch.zeros(d, ZC - o - H - 1, device=dev, dtype=E.W.dtype)
         ZW1T = torch.cat((self.j_layer.W.t(), self.lt_layer_1.W.t(), E.V1, pad), dim=1)
         ZW2T = torch.cat((self.j_layer.W.t(), self.lt_layer_2.W.t(), E.V2, pad), dim=1)
-        zb = torch.cat((self.j_layer.b, torch.zeros(ZC - o, device=dev)))
+        zb = torch.cat((self.j_layer.b, torch.zeros(ZC - o, device=dev, dtype=E.W.dtype)))
         return WbT, ZW1T, ZW2T, zb, self.attention_layer_1.W[0], self.attention_layer_2.W[0], E.b
 
     def forward(self, atoms_1, g_1, atoms_2, g_2, **_) -> Tuple[torch.Tensor, torch.Tensor]:
         if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
             raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        fast = getattr(self, "_fast", None)
+        if fast is not None:
+            return self._forward_fast(atoms_1, atoms_2, fast, 0)
         X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
         WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = self._kernel_weights()
         return NieCoattnFn.apply(X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cb, w1, w2, meta, self.hidden_dim,
@@ -187,7 +272,7 @@ class VQAParallelCoattention(NieFineCoattention):
         super().__init__(hidden_dim, out_dim, head, activation)
 
 
-class PoolingFineCoattention(nn.Module):
+class PoolingFineCoattention(_FinePlanMixin, nn.Module):
     """models/coattention/PoolingFineCoattention.py:13-81: same bilinear energy C as Nie; the atom
     weights are softmax(mean of C over the other side's padded positions); no head projections."""
 
@@ -207,16 +292,26 @@ class PoolingFineCoattention(nn.Module):
     def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
         if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
             raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        fast = getattr(self, "_fast", None)
+        if fast is not None:
+            return self._forward_fast(atoms_1, atoms_2, fast, 1)
         X1, X2, w1, w2, meta, _joint = pair_rows(atoms_1, atoms_2)
-        d, o, H = self.hidden_dim, self.out_dim, 1          # one (unused, zero-weight) head column keeps the row layout
+        WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = self._kernel_weights()
+        return NieCoattnFn.apply(X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cb, w1, w2, meta, self.hidden_dim, self.out_dim,
+                                 1, ACT[self.activation], 1)
+
+    def _heads(self) -> int:
+        return 1          # one (unused, zero-weight) head column keeps the row layout
+
+    def _kernel_weights(self):
+        d, o, H = self.hidden_dim, self.out_dim, 1
         ZC = _lib.lib().bmp_coattn_zcols(o, H)
         E = self.energy_layer
         dev = E.W.device
-        pad = torch.zeros(d, ZC - o - H - 1, device=dev)
-        zcol = torch.zeros(d, H, device=dev)
+        pad = torch.zeros(d, ZC - o - H - 1, device=dev, dtype=E.W.dtype)
+        zcol = torch.zeros(d, H, device=dev, dtype=E.W.dtype)
         ZW1T = torch.cat((self.j_layer.W.t(), zcol, E.V1, pad), dim=1)
         ZW2T = torch.cat((self.j_layer.W.t(), zcol, E.V2, pad), dim=1)
-        zb = torch.cat((self.j_layer.b, torch.zeros(ZC - o, device=dev)))
-        wa = torch.zeros(H, device=dev)
-        return NieCoattnFn.apply(X1, X2, E.W[:, :, 0].t(), ZW1T, ZW2T, zb, wa, wa, E.b, w1, w2, meta, d, o, H,
-                                 ACT[self.activation], 1)
+        zb = torch.cat((self.j_layer.b, torch.zeros(ZC - o, device=dev, dtype=E.W.dtype)))
+        wa = torch.zeros(H, device=dev, dtype=E.W.dtype)
+        return E.W[:, :, 0].t(), ZW1T, ZW2T, zb, wa, wa, E.b

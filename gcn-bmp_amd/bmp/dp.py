@@ -36,16 +36,24 @@ class _Unflatten(Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        parts = []
-        for g, shp in zip(grads, ctx.shapes):
-            if g is None:
-                n = 1
-                for k in shp:
-                    n *= k
-                parts.append(grads[0].new_zeros(n) if grads[0] is not None else torch.zeros(n))
-            else:
-                parts.append(g.reshape(-1))
-        return torch.cat(parts), None
+        some = next((g for g in grads if g is not None), None)
+        if some is None:
+            return None, None
+        sizes = []
+        for shp in ctx.shapes:
+            n = 1
+            for k in shp:
+                n *= k
+            sizes.append(n)
+        if all(g is not None for g in grads):
+            return torch.cat([g.reshape(-1) for g in grads]), None
+        flat = some.new_zeros(sum(sizes))         # parameters the layout plan manages arrive as None: one fill,
+        off = 0                                   # then only the autograd-managed slices are copied in
+        for g, n in zip(grads, sizes):
+            if g is not None:
+                flat[off:off + n].copy_(g.reshape(-1))
+            off += n
+        return flat, None
 
 
 class FlatAdam:
@@ -79,6 +87,9 @@ class FlatAdam:
         self.alpha, self.beta1, self.beta2, self.eps, self.wd = alpha, beta1, beta2, eps, weight_decay_rate
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.plan = None
+        self._plan_tried = False
+        self._gscale = 1.0
 
     def zero_grad(self) -> None:
         self.grad.zero_()
@@ -90,12 +101,45 @@ class FlatAdam:
         leaf = self.flat.detach().requires_grad_()
         self._leaf = leaf
         views = _Unflatten.apply(leaf, self.shapes)
-        return torch.func.functional_call(self.module, dict(zip(self.names, views)), args, kwargs)
+        plan = self._layout_plan()
+        hooked = []
+        if plan is not None:
+            # one launch: every kernel-layout weight array of the planned sub-modules; their weight gradients stay in
+            # the plan's buffers until collect_grads()
+            plan.prepare(self.flat)
+            tape = leaf[:1]
+            for prefix, mod in self._plan_sections:
+                mod._fast = (plan.P[prefix], plan.G[prefix], plan.state, tape)
+                hooked.append(mod)
+        try:
+            return torch.func.functional_call(self.module, dict(zip(self.names, views)), args, kwargs)
+        finally:
+            for mod in hooked:
+                mod._fast = None
+
+    def _layout_plan(self):
+        """bmp.plan.LayoutPlan over the sub-modules that support it (GGNN encoder, fine co-attention), built at the
+        first functional step on a GPU."""
+        if self._plan_tried or not self.flat.is_cuda:
+            return self.plan
+        self._plan_tried = True
+        from .plan import LayoutPlan
+        sections = []
+        for name, mod in self.module.named_modules():
+            if name and callable(getattr(mod, "plannable", None)) and mod.plannable() and hasattr(mod, "prepared_layouts"):
+                if all(p.requires_grad for p in mod.parameters()):
+                    sections.append((name + ".", mod))
+        if sections:
+            self._plan_sections = sections
+            self.plan = LayoutPlan(sections, self.names, self.shapes, self.flat.device)
+        return self.plan
 
     def collect_grads(self) -> None:
         g = self._leaf.grad
         self.grad = g if g is not None else torch.zeros_like(self.flat)
         self._leaf = None
+        if self.plan is not None:
+            self.plan.collect(self.grad)            # one launch: += the planned modules' parameter gradients
 
     def reattach(self) -> None:
         """Fold any .grad tensor that autograd (or a caller) replaced back into the flat buffer."""
@@ -117,12 +161,23 @@ class FlatAdam:
         mean over its own shard)."""
         if self.world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
-            self.grad.mul_(1.0 / self.world)
+            if self.grad.is_cuda:
+                self._gscale = 1.0 / self.world      # folded into the Adam kernel
+            else:
+                self.grad.mul_(1.0 / self.world)
 
     def step(self) -> None:
         self.t += 1
         a_t = self.alpha * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
         g = self.grad
+        if self.flat.is_cuda:                        # the whole update rule as one kernel over the flat buffers
+            from . import _lib
+            from ._lib import check, ptr, stream
+            check(_lib.lib().bmp_adam_step(ptr(self.flat), ptr(g), ptr(self.m), ptr(self.v), self.flat.numel(), a_t,
+                                           self.beta1, self.beta2, self.eps, self.wd, self._gscale, stream()),
+                  "bmp_adam_step")
+            self._gscale = 1.0
+            return
         self.m.mul_(self.beta1).add_(g, alpha=1.0 - self.beta1)
         self.v.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
         if self.wd:

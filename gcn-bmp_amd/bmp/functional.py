@@ -347,3 +347,108 @@ class LinearRowsFn(Function):
         check(L.bmp_linear_wgrad(ptr(X), K, ptr(dY), Nout, N, K, Nout, ptr(dWT), ptr(db), ptr(ws), nws, stream()),
               "bmp_linear_wgrad")
         return dX, dWT, db, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Prepared-weight forms (bmp/plan.py): weights arrive in kernel layout from the plan's one-launch gather and
+# the weight gradients stay in the plan's buffers (folded into the flat gradient by one more launch), so
+# autograd only carries the row tensors.  ``tape`` is a dummy 1-element tensor that requires grad: it makes
+# autograd run the backward of ops whose only differentiable input would have been a weight.
+# ---------------------------------------------------------------------------------------------------------
+class PEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, tape, W, ids, dW):
+        L = _lib.lib()
+        V, d = W.shape
+        N = ids.numel()
+        out = torch.empty(N, d, dtype=torch.float32, device=W.device)
+        check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, ptr(out), stream()), "bmp_embed_fwd")
+        ctx.ids, ctx.dW, ctx.V = ids, dW, V
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        dout = dout.contiguous()
+        N, d = dout.shape
+        ctx.dW.zero_()
+        check(L.bmp_embed_bwd(ptr(ctx.ids), ptr(dout), N, d, ctx.V, ptr(ctx.dW), stream()), "bmp_embed_bwd")
+        return None, None, None, None
+
+
+class PStepFn(Function):
+    """GGNNStepFn on prepared weights.  W: WTp, bE, ATp, UcTp, b, Wnat_p, A_p, Uc_p; G: o1, o2, dUcT, cs of the
+    step's weight group; ``state[gkey]`` says whether the group's buffers already hold a step of this backward."""
+
+    @staticmethod
+    def forward(ctx, h, pb, W, G, state, gkey, first):
+        L = _lib.lib()
+        require_rows(h, "step: h")
+        _check_pb(pb, h)
+        N, d = h.shape
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
+        m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
+        check(L.bmp_ggnn_step_fwd(ptr(h), pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+                                  ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
+                                  ptr(c), ptr(hout), stream()), "bmp_ggnn_step_fwd")
+        ctx.save_for_backward(h, m, rz, c)
+        ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dhout):
+        L = _lib.lib()
+        h, m, rz, c = ctx.saved_tensors
+        pb, W, G, first = ctx.pb, ctx.W, ctx.G, ctx.first
+        N, d = h.shape
+        dhout = dhout.contiguous()
+        dh = torch.empty(N, d, dtype=torch.float32, device=h.device)
+        gda = torch.empty(N, 7 * d, dtype=torch.float32, device=h.device)
+        check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
+                                  ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
+                                  ptr(dh), ptr(gda), stream()), "bmp_ggnn_step_bwd")
+        acc = 1 if ctx.state.get(ctx.gkey) else 0
+        nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
+        ws = _ws(nws, h.device)
+        check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(G["o1"]), ptr(G["o2"]),
+                                    ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+        ctx.state[ctx.gkey] = True
+        return dh, None, None, None, None, None, None
+
+
+class PReadoutFn(Function):
+    """ReadoutFn on prepared weights.  W: WT, b, Wnat; G: dWT, db."""
+
+    @staticmethod
+    def forward(ctx, h, h0, pb, W, G, act_j):
+        L = _lib.lib()
+        require_rows(h, "readout: h")
+        _check_pb(pb, h)
+        N, d = h.shape
+        d0 = h0.shape[1]
+        WT = W["WT"]
+        o = WT.shape[1] // 2
+        ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+        g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
+        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(W["b"]), act_j, ptr(pb.row_w),
+                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()),
+              "bmp_readout_fwd")
+        ctx.save_for_backward(h, h0, ij)
+        ctx.pb, ctx.W, ctx.G, ctx.act_j, ctx.o = pb, W, G, act_j, o
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        L = _lib.lib()
+        h, h0, ij = ctx.saved_tensors
+        pb, o, W, G = ctx.pb, ctx.o, ctx.W, ctx.G
+        dg = dg.contiguous()
+        N, d = h.shape
+        d0 = h0.shape[1]
+        dh, dh0 = torch.empty_like(h), torch.empty_like(h0)
+        nws = L.bmp_readout_bwd_ws_floats(pb.n_tiles, d, d0, o)
+        ws = _ws(nws, h.device)
+        check(L.bmp_readout_bwd(ptr(dg), ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(W["Wnat"]), ptr(ij), ctx.act_j,
+                                ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0),
+                                ptr(G["dWT"]), ptr(G["db"]), ptr(ws), nws, stream()), "bmp_readout_bwd")
+        return dh, dh0, None, None, None, None

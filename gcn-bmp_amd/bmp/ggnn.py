@@ -148,7 +148,7 @@ class GGNN(nn.Module):
     def _readout_weights(self, k: int):
         i, j = self.i_layers[k], self.j_layers[k]
         d = self.hidden_dim
-        WT = torch.cat((i.W.t(), torch.cat((j.W.t(), torch.zeros(d, self.out_dim, device=j.W.device)), dim=0)), dim=1)
+        WT = torch.cat((i.W.t(), torch.cat((j.W.t(), torch.zeros(d, self.out_dim, device=j.W.device, dtype=j.W.dtype)), dim=0)), dim=1)
         return WT.contiguous(), torch.cat((i.b, j.b))
 
     def readout(self, h, h0, pb, step=0):
@@ -156,12 +156,86 @@ class GGNN(nn.Module):
         WT, b = self._readout_weights(k)
         return Fn.ReadoutFn.apply(h, h0, WT, b, pb, Fn.ACT["identity"])
 
+    # ---- layout plan protocol (bmp/plan.py): the weight-layout code above as pure functions of the parameters ----
+    def plannable(self) -> bool:
+        return self.fused and not self.concat_hidden and Fn.step_supported(self.hidden_dim)
+
+    def _step_groups(self):
+        """(message layer, GRU mode) of every step, in step order (models/ggnn.py:220, first call after reset)."""
+        return [((0 if self.weight_tying else s), ("first" if s == 0 else "later")) for s in range(self.n_layers)]
+
+    def primary_layouts(self):
+        out = {"embed.W": self.embed.W}
+        for li, lin in enumerate(self.message_layers):
+            out[f"msg{li}.WT"], out[f"msg{li}.bE"] = message_kernel_weights(lin)
+        for mode in ("first", "later"):
+            out[f"gru_{mode}.AT"], UcT, out[f"gru_{mode}.b"] = self.update_layer.kernel_weights(first=(mode == "first"))
+        out["gru.UcT"] = UcT
+        out["ro.WT"], out["ro.b"] = self._readout_weights(0)
+        return out
+
+    def prepared_layouts(self):
+        p = self.primary_layouts()
+        out = {"embed.W": p["embed.W"], "gru.UcTp": Fn.pack_k4(p["gru.UcT"]), "gru.Uc_p": Fn.pack_k4(p["gru.UcT"].t()),
+               "ro.WT": p["ro.WT"], "ro.b": p["ro.b"], "ro.Wnat": p["ro.WT"].t().contiguous()}
+        for li in range(self.n_message_layer):
+            WT = p[f"msg{li}.WT"]
+            out[f"msg{li}.WTp"], out[f"msg{li}.bE"], out[f"msg{li}.Wnat_p"] = Fn.pack_k4(WT), p[f"msg{li}.bE"], Fn.pack_k4(WT.t())
+        for mode in ("first", "later"):
+            AT = p[f"gru_{mode}.AT"]
+            out[f"gru_{mode}.ATp"], out[f"gru_{mode}.b"], out[f"gru_{mode}.A_p"] = Fn.pack_k4(AT), p[f"gru_{mode}.b"], Fn.pack_k4(AT.t())
+        return out
+
+    def gk_spec(self):
+        d, o = self.hidden_dim, self.out_dim
+        spec = {"embed.dW": tuple(self.embed.W.shape), "ro.dWT": (2 * d, 2 * o), "ro.db": (2 * o,)}
+        for li, mode in dict.fromkeys(self._step_groups()):
+            for k, shp in (("o1", (d, 7 * d)), ("o2", (d, 3 * d)), ("dUcT", (d, d)), ("cs", (7 * d,))):
+                spec[f"g{li}_{mode}.{k}"] = shp
+        return spec
+
+    def primary_grads(self, gk):
+        """Gradients of the primary layouts as lists of terms taken from the kernels' buffers (the same slicing
+        GGNNStepFn.backward does)."""
+        d = self.hidden_dim
+        groups = list(dict.fromkeys(self._step_groups()))
+        out = {"embed.W": [gk["embed.dW"]], "ro.WT": [gk["ro.dWT"]], "ro.b": [gk["ro.db"]],
+               "gru.UcT": [gk[f"g{li}_{mode}.dUcT"] for li, mode in groups if mode == "later"]}
+        for li in range(self.n_message_layer):
+            mine = [f"g{l}_{mode}" for l, mode in groups if l == li]
+            out[f"msg{li}.WT"] = [gk[g + ".o1"][:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d) for g in mine]
+            out[f"msg{li}.bE"] = [gk[g + ".cs"][:4 * d].reshape(4, d) for g in mine]
+        for mode in ("first", "later"):
+            mine = [f"g{l}_{m}" for l, m in groups if m == mode]
+            out[f"gru_{mode}.AT"] = [torch.cat((gk[g + ".o1"][:, 4 * d:], gk[g + ".o2"]), dim=0) for g in mine]
+            out[f"gru_{mode}.b"] = [gk[g + ".cs"][4 * d:] for g in mine]
+        return out
+
+    def _forward_fast(self, pb, fast):
+        """The encoder on the plan's prepared weights: embed, fused steps, readout -- no layout work, no weight
+        gradients through autograd."""
+        P, G, state, tape = fast
+        h = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"])
+        h0 = h
+        for step, (li, mode) in enumerate(self._step_groups()):
+            W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
+                     b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])
+            g = f"g{li}_{mode}"
+            Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
+            h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0)
+        self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
+        return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
+                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"])
+
     def forward(self, atom_array, adj=None):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``
         (mb, 4, A, A), or a PackedMolBatch (then ``adj`` is ignored).  Returns (n_mols, out_dim)
         [(n_mols, n_layers*out_dim) with concat_hidden]."""
         dev = self.embed.W.device
         pb = as_packed(atom_array, adj, dev)
+        fast = getattr(self, "_fast", None)
+        if fast is not None:
+            return self._forward_fast(pb, fast)
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)                 # :603
         h0 = h                                                          # :612
         later = None

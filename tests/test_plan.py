@@ -1,0 +1,103 @@
+"""Layout plan (bmp/plan.py): the two gather tables against the modules' own layout code.
+
+CPU: the tables are derived by evaluating prepared_layouts() / primary_layouts() / primary_grads() on
+index-valued stand-ins; here they are replayed on random parameters and random kernel-gradient buffers and
+must reproduce (i) the layout functions exactly and (ii) autograd's parameter gradients of the same functions.
+GPU: a whole training step through the plan equals the eager autograd step (same kernels underneath).
+"""
+import numpy as np
+import pytest
+import torch
+
+from bmp.coattention import NieFineCoattention, PoolingFineCoattention
+from bmp.ggnn import GGNN
+from bmp.plan import LayoutPlan, gather_sum_host
+
+
+def _flat_of(mods):
+    names, shapes, chunks = [], [], []
+    for prefix, m in mods:
+        for n, p in m.named_parameters():
+            names.append(prefix + n); shapes.append(tuple(p.shape)); chunks.append(p.detach().reshape(-1))
+    return names, shapes, torch.cat(chunks)
+
+
+@pytest.mark.parametrize("tying,n_layers", [(True, 4), (False, 3), (True, 1)])
+def test_plan_tables_match_layout_code(tying, n_layers):
+    torch.manual_seed(11)
+    enc = GGNN(out_dim=12, hidden_dim=8, n_layers=n_layers, weight_tying=tying)
+    att = NieFineCoattention(hidden_dim=8, out_dim=12, head=3, activation="tanh")
+    pool = PoolingFineCoattention(hidden_dim=8, out_dim=12)
+    with torch.no_grad():
+        for m in (enc, att, pool):
+            for p in m.parameters():
+                p.copy_(torch.randn_like(p))
+    mods = [("graph_conv.", enc), ("attn.", att), ("pool.", pool)]
+    names, shapes, flat = _flat_of(mods)
+    plan = LayoutPlan(mods, names, shapes, "cpu")
+    # (i) prepare == the layout functions, bit for bit
+    plan.prepare(flat)
+    for prefix, m in mods:
+        with torch.no_grad():
+            ref = m.prepared_layouts()
+        assert set(ref) == set(plan.P[prefix])
+        for k, v in ref.items():
+            assert torch.equal(plan.P[prefix][k], v.contiguous()), (prefix, k)
+    # (ii) collect == autograd through primary_layouts with the kernels' buffers as upstream gradients
+    plan.gk.copy_(torch.randn_like(plan.gk))
+    got = torch.zeros_like(flat)
+    plan.collect(got)
+    want = []
+    for prefix, m in mods:
+        params = list(m.parameters())
+        prim = m.primary_layouts()
+        pg = m.primary_grads(plan.G[prefix])
+        loss = sum((prim[k] * t).sum() for k in prim for t in pg[k])
+        gs = torch.autograd.grad(loss, params, allow_unused=True)
+        want += [(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]
+    want = torch.cat(want)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), (got - want).abs().max()
+
+
+def test_gather_sum_host_semantics():
+    src = torch.tensor([1.0, 2.0, 4.0])
+    tab = np.array([[0, 2, -1], [1, -1, -1]], dtype=np.int32)
+    assert gather_sum_host(src, tab).tolist() == [3.0, 4.0, 0.0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attn", ["nie", "pool"])
+def test_planned_step_equals_eager_step(attn):
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(40, seed=3, n_lo=4, n_hi=40, n_mean=14)
+    ms = packed.MolStore(store)
+    i1, i2 = np.arange(0, 16), np.arange(16, 32)
+    pb = packed.pack_from_store(ms, [i1, i2], device=dev)
+    t = (torch.arange(16, device=dev) % 2).int().view(-1, 1)
+    torch.manual_seed(1)
+    model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=3, attn=attn, head=4).to(dev)
+    # eager: module parameters, autograd through every layout op
+    y = model(pb)
+    model.loss(y, t).backward()
+    # (the fine co-attention ignores g_1 / g_2, nie_coattention.py:335-370: the readout gets no gradient)
+    eager = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()]).clone()
+    y_eager = y.detach().clone()
+    # planned: flat buffer, two gather launches
+    opt = FlatAdam(model, alpha=1e-3)
+    y2 = opt.functional_forward(pb)
+    assert opt.plan is not None and {"graph_conv.", "attn."} <= set(opt.plan.P)
+    model.loss(y2, t).backward()
+    opt.collect_grads()
+    assert torch.equal(y2.detach(), y_eager)
+    scale = eager.abs().max().item()
+    assert (opt.grad - eager).abs().max().item() <= 1e-5 * scale
+    # and the fused Adam kernel against the update rule written out
+    p0, g = opt.flat.clone(), opt.grad.clone()
+    opt.step()
+    m = 0.1 * g; v = 0.001 * g * g
+    a_t = 1e-3 * (1 - 0.999) ** 0.5 / (1 - 0.9)
+    want = p0 - a_t * m / (v.sqrt() + 1e-8)
+    assert torch.allclose(opt.flat, want, rtol=1e-5, atol=1e-7)
