@@ -49,6 +49,11 @@ SIGNATURES = {
     "bmp_rowbcast_bwd": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "bmp_rowdot_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "bmp_rowdot_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),
+    "bmp_mlp_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_sce_fwd": (_I, [_P, _P, _I, _P, _P, _P]),
+    "bmp_sce_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "bmp_gather_sum": (_I, [_P, _I, _P, _P, _I, _I, _P]),
     "bmp_adam_step": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P]),
     "bmp_coattn_zcols": (_I, [_I, _I]),

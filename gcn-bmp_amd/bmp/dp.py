@@ -25,6 +25,7 @@ class _Unflatten(Function):
     @staticmethod
     def forward(ctx, flat, shapes):
         ctx.shapes = shapes
+        ctx.set_materialize_grads(False)          # unused parameters arrive as None, not as one zero-fill launch each
         outs, off = [], 0
         for shp in shapes:
             n = 1

@@ -1,14 +1,117 @@
-"""Link predictor ``MLP`` with the reference's signature (models/mlp.py:20-45).
+"""Link predictor ``MLP`` with the reference's signature (models/mlp.py:20-45) and the pair loss.
 
-(B, 2*out_dim) -> 32 -> 16 -> class_num on B rows is < 0.1 % of the path's flops
-(SURVEY.md 2.3 K10); it runs as plain torch ops on the device.
+On the device the whole MLP is one forward launch and two backward launches (bmp_mlp_fwd / bmp_mlp_bwd) and the
+sigmoid cross entropy one launch each way, instead of ~40 framework launches of a few microseconds.  Host tensors
+(the CPU tests of the data-parallel plumbing) take the plain torch ops.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 from torch import nn
+from torch.autograd import Function
 
 from .ggnn import Linear
+
+_MAXL, _MAXW, _MAXIN = 4, 64, 1024
+
+
+def _parr(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class MLPFn(Function):
+    """relu-MLP on [x1 | x2].  ``G`` (a dict name -> tensor from bmp.plan) receives the weight gradients instead of
+    autograd when given; ``tape`` is the plan's dummy differentiable input."""
+
+    @staticmethod
+    def forward(ctx, tape, x1, x2, G, *wb):
+        from . import _lib
+        from ._lib import check, ptr, stream
+        L = _lib.lib()
+        nl = len(wb) // 2
+        Ws = [w.contiguous() for w in wb[:nl]]
+        bs = [None if b is None else b.contiguous() for b in wb[nl:]]
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        B, d1 = x1.shape
+        d2 = 0 if x2 is None else x2.shape[1]
+        dims = [d1 + d2] + [w.shape[0] for w in Ws]
+        cd = (ctypes.c_int * len(dims))(*dims)
+        acts = [torch.empty(B, n, dtype=torch.float32, device=x1.device) for n in dims[1:]]
+        check(L.bmp_mlp_fwd(ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(bs), _parr(acts), stream()), "bmp_mlp_fwd")
+        ctx.save_for_backward(x1, *( [x2] if x2 is not None else [] ), *Ws, *acts)
+        ctx.meta = (nl, dims, x2 is not None, [b is not None for b in bs], G)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from ._lib import check, ptr, stream
+        L = _lib.lib()
+        nl, dims, has2, has_b, G = ctx.meta
+        sv = list(ctx.saved_tensors)
+        x1 = sv.pop(0)
+        x2 = sv.pop(0) if has2 else None
+        Ws, acts = sv[:nl], sv[nl:]
+        B, d1 = x1.shape
+        d2 = dims[0] - d1
+        dev = x1.device
+        dy = dy.contiguous()
+        cd = (ctypes.c_int * len(dims))(*dims)
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if has2 else None
+        if G is not None:
+            dW = [G[f"dW{l}"] for l in range(nl)]
+            db = [G[f"db{l}"] if has_b[l] else None for l in range(nl)]
+        else:
+            dW = [torch.empty_like(w) for w in Ws]
+            db = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) if has_b[l] else None for l, w in enumerate(Ws)]
+        nws = L.bmp_mlp_bwd_ws_floats(B, nl, cd)
+        ws = torch.empty(max(nws, 4), dtype=torch.float32, device=dev)
+        check(L.bmp_mlp_bwd(ptr(dy), ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(acts), ptr(dx1), ptr(dx2),
+                            _parr(dW), _parr(db), ptr(ws), nws, stream()), "bmp_mlp_bwd")
+        if G is not None:
+            return (None, dx1, dx2, None) + (None,) * (2 * nl)
+        return (None, dx1, dx2, None) + tuple(dW) + tuple(db)
+
+
+class SCEFn(Function):
+    """chainer.functions.sigmoid_cross_entropy (train_ddi_modify.py:285)."""
+
+    @staticmethod
+    def forward(ctx, y, t):
+        from . import _lib
+        from ._lib import check, ptr, stream
+        y = y.contiguous()
+        t = t.to(torch.int32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=y.device)
+        sums = torch.empty(2, dtype=torch.float32, device=y.device)         # numerator | count
+        check(_lib.lib().bmp_sce_fwd(ptr(y), ptr(t), y.numel(), ptr(loss), ptr(sums), stream()), "bmp_sce_fwd")
+        ctx.save_for_backward(y, t, sums)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import _lib
+        from ._lib import check, ptr, stream
+        y, t, sums = ctx.saved_tensors
+        dy = torch.empty_like(y)
+        gout = gout.contiguous().to(torch.float32)
+        check(_lib.lib().bmp_sce_bwd(ptr(y), ptr(t), y.numel(), ptr(sums), ptr(gout), ptr(dy), stream()), "bmp_sce_bwd")
+        return dy, None
+
+
+def sigmoid_cross_entropy(y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """Mean over the elements with t != -1 of softplus(y) - t*y."""
+    if y.is_cuda:
+        return SCEFn.apply(y, t)
+    tf = t.to(y.dtype)
+    mask = t != -1
+    loss = torch.nn.functional.softplus(y) - tf * y
+    loss = torch.where(mask, loss, torch.zeros_like(loss))
+    return loss.sum() / mask.sum().clamp(min=1).to(y.dtype)
 
 
 class MLP(nn.Module):
@@ -21,9 +124,54 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList([Linear(dims[i], dims[i + 1]) for i in range(len(hidden_dims))])
         self.l_out = Linear(dims[-1], out_dim)
         self.activation = activation
+        self.in_dim, self.out_dim = in_dim, out_dim
 
-    def forward(self, x):
-        h = x
+    def _linears(self):
+        return list(self.layers) + [self.l_out]
+
+    def _kernel_ok(self) -> bool:
+        ls = self._linears()
+        return (self.activation in (torch.relu, torch.nn.functional.relu) and len(ls) <= _MAXL and self.in_dim <= _MAXIN
+                and all(l.out_size <= _MAXW for l in ls))
+
+    # ---- layout plan protocol (bmp/plan.py): identity layouts, the kernels write the gradients in place ----
+    def plannable(self) -> bool:
+        return self._kernel_ok()
+
+    def primary_layouts(self):
+        out = {}
+        for k, l in enumerate(self._linears()):
+            out[f"W{k}"] = l.W
+            out[f"b{k}"] = l.b
+        return out
+
+    prepared_layouts = primary_layouts
+
+    def gk_spec(self):
+        spec = {}
+        for k, l in enumerate(self._linears()):
+            spec[f"dW{k}"] = tuple(l.W.shape)
+            spec[f"db{k}"] = tuple(l.b.shape)
+        return spec
+
+    def primary_grads(self, gk):
+        out = {}
+        for k in range(len(self._linears())):
+            out[f"W{k}"] = [gk[f"dW{k}"]]
+            out[f"b{k}"] = [gk[f"db{k}"]]
+        return out
+
+    def forward(self, x, x2=None):
+        """models/mlp.py:40-45.  ``x2``: optional second half of the input row ([x | x2] without the concatenation)."""
+        ls = self._linears()
+        if x.is_cuda and self._kernel_ok():
+            fast = getattr(self, "_fast", None)
+            if fast is not None:
+                P, G, _state, tape = fast
+                wb = [P[f"W{k}"] for k in range(len(ls))] + [P[f"b{k}"] for k in range(len(ls))]
+                return MLPFn.apply(tape, x, x2, G, *wb)
+            return MLPFn.apply(None, x, x2, None, *[l.W for l in ls], *[l.b for l in ls])
+        h = x if x2 is None else torch.cat((x, x2), dim=-1)
         for l in self.layers:                                   # models/mlp.py:42-43
             h = self.activation(torch.nn.functional.linear(h, l.W, l.b))
         return torch.nn.functional.linear(h, self.l_out.W, self.l_out.b)

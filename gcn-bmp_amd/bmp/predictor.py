@@ -9,18 +9,8 @@ import torch
 from torch import nn
 
 from .ggnn import GGNN, PackedAtoms, as_packed
-from .mlp import MLP
+from .mlp import MLP, sigmoid_cross_entropy      # noqa: F401  (re-exported: the pair loss)
 from .packed import PackedMolBatch
-
-
-def sigmoid_cross_entropy(y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-    """chainer.functions.sigmoid_cross_entropy (train_ddi_modify.py:285): mean over the
-    elements with t != -1 of softplus(y) - t*y."""
-    tf = t.to(y.dtype)
-    mask = t != -1
-    loss = torch.nn.functional.softplus(y) - tf * y
-    loss = torch.where(mask, loss, torch.zeros_like(loss))
-    return loss.sum() / mask.sum().clamp(min=1).to(y.dtype)
 
 
 class GraphConvPredictorForPair(nn.Module):
@@ -51,9 +41,7 @@ class GraphConvPredictorForPair(nn.Module):
         if self.attn is not None:
             g1, g2 = self.attn(at1, g1, at2, g2, mol0=mol0)                  # train_binary.py:96
         self.g1, self.g2 = g1, g2
-        if isinstance(self.mlp, MLP):
-            return self.mlp(torch.cat((g1, g2), dim=-1))                     # :98-101
-        return self.mlp(g1, g2)                                              # NTN / HolE / ... :102-116
+        return self.mlp(g1, g2)          # MLP on [g1 | g2] :98-101 (no concatenation copy); NTN / HolE / ... :102-116
 
     def predict(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
         """train_binary.py:120-127 (sigmoid under no-backprop)."""

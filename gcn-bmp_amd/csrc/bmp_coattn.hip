@@ -728,12 +728,11 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     {
         WGArgs g{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0};
         if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
-        WGArgs g1{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0};
+        // dzb = column sums of dZ1 and dZ2: they ride along with the two GEMMs that read those arrays anyway
+        WGArgs g1{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0, dzb, 0};
         if ((rc = bmp_launch_wgrad(g1, slab, st))) return rc;
-        WGArgs g2{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0};
+        WGArgs g2{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb, 1};
         if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
     }
-    if ((rc = bmp_launch_colsum(dZ1, ZC, N1, ZC, dzb, 0, slab, st))) return rc;
-    if ((rc = bmp_launch_colsum(dZ2, ZC, N2, ZC, dzb, 1, slab, st))) return rc;
     return bmp_launch_colsum(dpart, 2 * H + 1, B, 2 * H + 1, dwa, 0, slab, st);
 }

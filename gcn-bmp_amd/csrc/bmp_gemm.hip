@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WGKArgs a) {
 // 64 elements x 4 slab lanes per workgroup; fixed summation order (bitwise reproducible).
 // Slabs are [S][K][Nn]; row `cs_row` (if >= 0) holds column sums and goes to cs_out instead of out.
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slab, int S, int K, int Nn, float* out,
-                                                      int ldo, int accumulate, int cs_row, float* cs_out) {
+                                                      int ldo, int accumulate, int cs_row, float* cs_out, int cs_accumulate) {
     __shared__ float red[4][64];
     const size_t total = (size_t)K * Nn;
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
             v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
             const int i = (int)(idx / Nn), j = (int)(idx % Nn);
             float* o = (i == cs_row) ? (cs_out + j) : (out + (size_t)i * ldo + j);
-            *o = accumulate ? (*o + v) : v;
+            *o = (i == cs_row ? cs_accumulate : accumulate) ? (*o + v) : v;
         }
         __syncthreads();
     }
@@ -464,7 +464,7 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
         int blocks = (int)((total + 63) / 64);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, ws, S, Krows, a.Nn, a.out, a.ldo, a.accumulate,
-                           want_cs ? a.K : -1, a.cs);
+                           want_cs ? a.K : -1, a.cs, a.accumulate | a.cs_accumulate);
         BMP_LAUNCH_CHECK();
         return 0;
     }
@@ -484,9 +484,9 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     int blocks = (int)((total + 63) / 64);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, ws, S, a.K, a.Nn, a.out, a.ldo, a.accumulate, -1,
-                       (float*)nullptr);
+                       (float*)nullptr, 0);
     BMP_LAUNCH_CHECK();
-    if (a.cs) return bmp_launch_colsum(a.dY, a.ldy, a.N, a.Nn, a.cs, a.accumulate, ws, st);
+    if (a.cs) return bmp_launch_colsum(a.dY, a.ldy, a.N, a.Nn, a.cs, a.accumulate | a.cs_accumulate, ws, st);
     return 0;
 }
 
@@ -509,9 +509,9 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dY, in
 }
 
 static void colsum_plan(int N, int& S, int& rps) {
-    S = N / 512;
+    S = N / 64;                 // a split walks its rows four at a time: keep the dependent chain short
     if (S < 1) S = 1;
-    if (S > 128) S = 128;
+    if (S > 256) S = 256;
     rps = (N + S - 1) / S;
     S = (N + rps - 1) / rps;
 }
@@ -529,7 +529,7 @@ int bmp_launch_colsum(const float* dY, int ldy, int N, int Nn, float* out, int a
     hipLaunchKernelGGL(k_colsum, dim3((Nn + 63) / 64, S), dim3(256), 0, st, dY, ldy, N, Nn, rps, ws);
     BMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_reduce_slabs, dim3((Nn + 63) / 64), dim3(256), 0, st, ws, S, 1, Nn, out, Nn, accumulate, -1,
-                       (float*)nullptr);
+                       (float*)nullptr, 0);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -58,6 +58,7 @@ struct WGArgs {
     float* out; int ldo;             // [K x Nn]
     int accumulate;
     float* cs;                       // optional [Nn]: column sums of dY (bias gradient), same accumulate flag
+    int cs_accumulate;               // ... or accumulated regardless of `accumulate` when != 0
 };
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);

@@ -1,0 +1,262 @@
+// Link-predictor tail of the pair path as a handful of launches: MLP (models/mlp.py:20-45: Linear -> relu -> ... ->
+// Linear on [g1 | g2]) forward / backward and sigmoid cross entropy (chainer.functions.sigmoid_cross_entropy,
+// train_ddi_modify.py:285).  The arithmetic is tiny (B x 256 -> 32 -> 16 -> C on B ~ 1000 rows); what it cost as
+// framework ops was ~40 launches of a few microseconds each per step.  Plain fp32 FMA, fixed summation orders.
+#include <string.h>
+#include "bmp_common.h"
+
+#define MLP_MAXL 4          // Linear layers
+#define MLP_MAXW 64         // widest hidden / output layer
+#define MLP_MAXIN 1024      // widest input
+#define MLP_FR 8            // rows per workgroup, forward
+#define MLP_BR 16           // rows per workgroup, backward
+
+struct MlpArgs {
+    const float* x1; const float* x2; int d1, d2;        // input row = [x1 row | x2 row]
+    int B, nl;
+    int dims[MLP_MAXL + 1];
+    const float* W[MLP_MAXL]; const float* b[MLP_MAXL];   // W[l] [dims[l+1] x dims[l]] (reference layout), b may be null
+    float* act[MLP_MAXL];                                 // act[l] [B x dims[l+1]]: relu outputs, last = logits
+    // backward
+    const float* dy; float* dx1; float* dx2; float* slab; int slab_stride;
+};
+
+__global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
+    __shared__ float buf[2][MLP_FR][MLP_MAXIN];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * MLP_FR;
+    const int in0 = a.dims[0];
+    for (int idx = tid; idx < MLP_FR * in0; idx += 256) {
+        const int r = idx / in0, k = idx % in0;
+        const int row = row0 + r;
+        float v = 0.f;
+        if (row < a.B) v = k < a.d1 ? a.x1[(size_t)row * a.d1 + k] : a.x2[(size_t)row * a.d2 + (k - a.d1)];
+        buf[0][r][k] = v;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int l = 0; l < a.nl; ++l) {
+        const int ni = a.dims[l], no = a.dims[l + 1];
+        const float* __restrict__ W = a.W[l];
+        const float* __restrict__ bb = a.b[l];
+        const bool last = l == a.nl - 1;
+        for (int idx = tid; idx < MLP_FR * no; idx += 256) {
+            const int r = idx / no, j = idx % no;
+            float acc = bb ? bb[j] : 0.f;
+            const float* w = W + (size_t)j * ni;
+            const float* x = buf[cur][r];
+            for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
+            if (!last) acc = acc > 0.f ? acc : 0.f;
+            buf[cur ^ 1][r][j] = acc;
+            if (row0 + r < a.B) a.act[l][(size_t)(row0 + r) * no + j] = acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// slab layout per workgroup: for every layer l: dW[l] [no x ni] then db[l] [no]
+__global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
+    __shared__ float xin[MLP_BR][MLP_MAXIN];              // layer-0 input rows
+    __shared__ float hid[MLP_MAXL][MLP_BR][MLP_MAXW];     // relu outputs of the hidden layers
+    __shared__ float dcur[2][MLP_BR][MLP_MAXW];           // gradient w.r.t. a layer's pre-activation output
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * MLP_BR;
+    const int in0 = a.dims[0];
+    for (int idx = tid; idx < MLP_BR * in0; idx += 256) {
+        const int r = idx / in0, k = idx % in0, row = row0 + r;
+        float v = 0.f;
+        if (row < a.B) v = k < a.d1 ? a.x1[(size_t)row * a.d1 + k] : a.x2[(size_t)row * a.d2 + (k - a.d1)];
+        xin[r][k] = v;
+    }
+    for (int l = 0; l + 1 < a.nl; ++l) {
+        const int no = a.dims[l + 1];
+        for (int idx = tid; idx < MLP_BR * no; idx += 256) {
+            const int r = idx / no, j = idx % no, row = row0 + r;
+            hid[l][r][j] = row < a.B ? a.act[l][(size_t)row * no + j] : 0.f;
+        }
+    }
+    {
+        const int no = a.dims[a.nl];
+        for (int idx = tid; idx < MLP_BR * no; idx += 256) {
+            const int r = idx / no, j = idx % no, row = row0 + r;
+            dcur[0][r][j] = row < a.B ? a.dy[(size_t)row * no + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    float* slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
+    int off_l[MLP_MAXL];
+    {
+        int o = 0;
+        for (int l = 0; l < a.nl; ++l) { off_l[l] = o; o += a.dims[l + 1] * (a.dims[l] + 1); }
+    }
+    int cur = 0;
+    for (int l = a.nl - 1; l >= 0; --l) {
+        const int ni = a.dims[l], no = a.dims[l + 1];
+        const float* __restrict__ W = a.W[l];
+        // weight / bias gradient partials of this workgroup's rows
+        float* dW = slab + off_l[l];
+        for (int idx = tid; idx < no * ni; idx += 256) {
+            const int j = idx / ni, k = idx % ni;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < MLP_BR; ++r) acc += dcur[cur][r][j] * (l == 0 ? xin[r][k] : hid[l - 1][r][k]);
+            dW[idx] = acc;
+        }
+        for (int j = tid; j < no; j += 256) {
+            float acc = 0.f;
+            for (int r = 0; r < MLP_BR; ++r) acc += dcur[cur][r][j];
+            dW[no * ni + j] = acc;
+        }
+        // gradient w.r.t. the layer input
+        if (l > 0) {
+            for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
+                const int r = idx / ni, k = idx % ni;
+                float acc = 0.f;
+                for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
+                dcur[cur ^ 1][r][k] = hid[l - 1][r][k] > 0.f ? acc : 0.f;
+            }
+        } else {
+            for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
+                const int r = idx / ni, k = idx % ni, row = row0 + r;
+                if (row >= a.B) continue;
+                float acc = 0.f;
+                for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
+                if (k < a.d1) a.dx1[(size_t)row * a.d1 + k] = acc;
+                else a.dx2[(size_t)row * a.d2 + (k - a.d1)] = acc;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// out[i] = sum over workgroup slabs, fixed order; the outputs are scattered to per-layer arrays by the host
+// through pointer/offset pairs
+struct MlpRedArgs { const float* slab; int nslab, stride; float* dW[MLP_MAXL]; float* db[MLP_MAXL]; int off[MLP_MAXL + 1]; int nw[MLP_MAXL]; int nl; };
+__global__ __launch_bounds__(256) void k_mlp_reduce(MlpRedArgs a) {
+    const int total = a.off[a.nl];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < a.nslab; ++s) v += a.slab[(size_t)s * a.stride + i];
+        int l = 0;
+        while (l + 1 < a.nl && i >= a.off[l + 1]) ++l;
+        const int loc = i - a.off[l];
+        if (loc < a.nw[l]) a.dW[l][loc] = v;
+        else if (a.db[l]) a.db[l][loc - a.nw[l]] = v;
+    }
+}
+
+static int mlp_fill(MlpArgs& a, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                    const float* const* W, const float* const* b, float* const* act) {
+    memset(&a, 0, sizeof(a));
+    BMP_REQUIRE(nl >= 1 && nl <= MLP_MAXL && B > 0 && x1 && d1 > 0 && d2 >= 0 && (d2 == 0 || x2));
+    BMP_REQUIRE(dims[0] == d1 + d2 && dims[0] <= MLP_MAXIN);
+    for (int l = 0; l < nl; ++l) {
+        BMP_REQUIRE(dims[l + 1] > 0 && dims[l + 1] <= MLP_MAXW && W[l] && act[l]);
+        a.W[l] = W[l]; a.b[l] = b ? b[l] : nullptr; a.act[l] = act[l];
+    }
+    for (int l = 0; l <= nl; ++l) a.dims[l] = dims[l];
+    a.x1 = x1; a.x2 = x2; a.d1 = d1; a.d2 = d2; a.B = B; a.nl = nl;
+    return 0;
+}
+
+// Forward.  x = [x1 (B x d1) | x2 (B x d2)] (x2 may be NULL with d2 = 0); dims[0..nl] = layer widths, dims[0] = d1 + d2;
+// W, b, act: HOST arrays of nl device pointers (W[l] [dims[l+1] x dims[l]], b[l] [dims[l+1]] or NULL,
+// act[l] [B x dims[l+1]] = relu(...) for l < nl-1, logits for the last).
+extern "C" int bmp_mlp_fwd(const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                           const float* const* W, const float* const* b, float* const* act, hipStream_t st) {
+    MlpArgs a;
+    int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, b, act);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mlp_fwd, dim3((B + MLP_FR - 1) / MLP_FR), dim3(256), 0, st, a);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t bmp_mlp_bwd_ws_floats(int B, int nl, const int* dims) {
+    size_t per = 0;
+    for (int l = 0; l < nl; ++l) per += (size_t)dims[l + 1] * (dims[l] + 1);
+    return per * ((B + MLP_BR - 1) / MLP_BR);
+}
+
+// Backward from dy [B x dims[nl]]: dx1, dx2, and per layer dW[l], db[l] (HOST arrays of device pointers; db[l] may be NULL).
+extern "C" int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                           const float* const* W, float* const* act, float* dx1, float* dx2, float* const* dW,
+                           float* const* db, float* ws, size_t ws_floats, hipStream_t st) {
+    MlpArgs a;
+    int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, nullptr, act);
+    if (rc) return rc;
+    BMP_REQUIRE(dy && dx1 && (d2 == 0 || dx2) && dW && ws && ws_floats >= bmp_mlp_bwd_ws_floats(B, nl, dims));
+    const int nwg = (B + MLP_BR - 1) / MLP_BR;
+    MlpRedArgs r; memset(&r, 0, sizeof(r));
+    int off = 0;
+    for (int l = 0; l < nl; ++l) {
+        BMP_REQUIRE(dW[l] != nullptr);
+        r.off[l] = off; r.nw[l] = dims[l + 1] * dims[l]; r.dW[l] = dW[l]; r.db[l] = db ? db[l] : nullptr;
+        off += dims[l + 1] * (dims[l] + 1);
+    }
+    r.off[nl] = off; r.nl = nl; r.slab = ws; r.nslab = nwg; r.stride = off;
+    a.dy = dy; a.dx1 = dx1; a.dx2 = dx2; a.slab = ws; a.slab_stride = off;
+    hipLaunchKernelGGL(k_mlp_bwd, dim3(nwg), dim3(256), 0, st, a);
+    BMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 255) / 256), dim3(256), 0, st, r);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- sigmoid cross entropy: loss = mean over elements with t != -1 of softplus(y) - t*y ----
+// One workgroup, fixed-order tree: sums[0] = loss numerator, sums[1] = count; loss[0] = sums[0] / max(count, 1).
+__global__ __launch_bounds__(1024) void k_sce_fwd(const float* __restrict__ y, const int* __restrict__ t, int n, float* loss,
+                                                  float* sums) {
+    __shared__ float s0[1024], s1[1024];
+    float acc = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int ti = t[i];
+        if (ti != -1) {
+            const float yi = y[i];
+            const float sp = (yi > 0.f ? yi : 0.f) + log1pf(expf(-fabsf(yi)));      // softplus, stable
+            acc += sp - (float)ti * yi;
+            cnt += 1.f;
+        }
+    }
+    s0[threadIdx.x] = acc; s1[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) { s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = s0[0]; sums[1] = s1[0];
+        loss[0] = s0[0] / (s1[0] > 1.f ? s1[0] : 1.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sce_bwd(const float* __restrict__ y, const int* __restrict__ t, int n,
+                                                 const float* __restrict__ sums, const float* __restrict__ gout,
+                                                 float* __restrict__ dy) {
+    const float scale = gout[0] / (sums[1] > 1.f ? sums[1] : 1.f);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int ti = t[i];
+        float g = 0.f;
+        if (ti != -1) g = (1.f / (1.f + expf(-y[i])) - (float)ti) * scale;
+        dy[i] = g;
+    }
+}
+
+extern "C" int bmp_sce_fwd(const float* y, const int* t, int n, float* loss, float* sums, hipStream_t st) {
+    BMP_REQUIRE(n > 0 && y && t && loss && sums);
+    hipLaunchKernelGGL(k_sce_fwd, dim3(1), dim3(1024), 0, st, y, t, n, loss, sums);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int bmp_sce_bwd(const float* y, const int* t, int n, const float* sums, const float* gout, float* dy,
+                           hipStream_t st) {
+    BMP_REQUIRE(n > 0 && y && t && sums && gout && dy);
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_sce_bwd, dim3(blocks), dim3(256), 0, st, y, t, n, sums, gout, dy);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}

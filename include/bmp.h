@@ -163,6 +163,21 @@ int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, 
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
                        bmp_stream_t stream);
 
+/* ---- link predictor tail: MLP (models/mlp.py:20-45: Linear -> relu -> ... -> Linear on [g1 | g2], train_binary.py:98-101)
+ * and sigmoid cross entropy (chainer.functions.sigmoid_cross_entropy, train_ddi_modify.py:285) ----
+ * x = [x1 (B x d1) | x2 (B x d2)] (x2 NULL when d2 = 0); dims[0..nl] layer widths (dims[0] = d1 + d2 <= 1024, the others
+ * <= 64, nl <= 4); W, b, act, dW, db are HOST arrays of nl device pointers: W[l] [dims[l+1] x dims[l]] (reference layout),
+ * act[l] [B x dims[l+1]] (relu outputs, the last one = logits).  sce: loss[0] = mean over t != -1 of softplus(y) - t*y,
+ * sums[2] = numerator, count (kept for the backward); dy = gout[0] * (sigmoid(y) - t) / count. */
+int bmp_mlp_fwd(const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims, const float* const* W,
+                const float* const* b, float* const* act, bmp_stream_t stream);
+size_t bmp_mlp_bwd_ws_floats(int B, int nl, const int* dims);
+int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                const float* const* W, float* const* act, float* dx1, float* dx2, float* const* dW, float* const* db,
+                float* ws, size_t ws_floats, bmp_stream_t stream);
+int bmp_sce_fwd(const float* y, const int* t, int n, float* loss, float* sums, bmp_stream_t stream);
+int bmp_sce_bwd(const float* y, const int* t, int n, const float* sums, const float* gout, float* dy, bmp_stream_t stream);
+
 /* ---- host glue of a training step (no counterpart kernels in the reference: there the layout changes are Chainer
  * function nodes and the optimizer is chainer.optimizers.Adam, train_ddi_modify.py:289) ----
  * bmp_gather_sum: dst[i] (=|+=) sum_k src[idx[k*n + i]] over table entries >= 0 (idx is [K][n] int32).  One launch
