@@ -37,13 +37,15 @@ PEAK_HBM_GBS = 8000.0
 
 def algorithmic_flops_per_pair(n_atoms_per_pair: float, d=D, T=T_STEPS, o=O, head=HEAD, n1=None, n2=None):
     """fwd per atom-step 26 d^2 (message 8 d^2 + GRU 18 d^2), readout 6 d^2 per atom,
-    Nie co-attention, MLP; fwd+bwd = 3 x fwd.  Real atoms only (no pad/dead rows, no folding credit)."""
+    Nie co-attention, MLP; fwd+bwd = 3 x fwd.  Real atoms only (no pad/dead rows, no folding credit).
+    The readout counts ONCE: the fine co-attention ignores g_1 / g_2 (nie_coattention.py:335-370), so the readout
+    is computed forward (as the reference does) but no gradient ever reaches it -- there is no readout backward."""
     half = n_atoms_per_pair / 2.0
     ggnn = 26.0 * d * d * n_atoms_per_pair * T
     readout = 6.0 * d * o * n_atoms_per_pair
     co = 2.0 * (half * d * d + half * half * d + n_atoms_per_pair * d * o + 2 * n_atoms_per_pair * head * d)
     mlp = 2.0 * (2 * o * 32 + 32 * 16 + 16)
-    return 3.0 * (ggnn + readout + co + mlp)
+    return 3.0 * (ggnn + co + mlp) + readout
 
 
 def algorithmic_bytes_per_pair(n_atoms_per_pair: float, n_edges_per_pair: float, d=D, T=T_STEPS):
@@ -202,11 +204,13 @@ def main():
             # passes of this same command, committed under profiles/), not measurable from inside this process
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")))
                 key = {5: "k_ggnn_step_fwd<128, false>", 6: "k_ggnn_step_bwd<128, false>", 2: "k_wgrad_lds<false>",
                        1: "k_rowgemm<1, 4, 1, 0>"}.get(cls)
                 if key in pmc:
-                    traffic = round((pmc[key]["FETCH_SIZE_per_launch"] + pmc[key]["WRITE_SIZE_per_launch"]) * 1024)
+                    # counters are in KiB; gfx950 tallies a 16-byte-per-lane streaming read at half its bytes
+                    # (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE is doubled, WRITE_SIZE taken as is
+                    traffic = round((2.0 * pmc[key]["FETCH_SIZE_per_launch"] + pmc[key]["WRITE_SIZE_per_launch"]) * 1024)
             except (OSError, ValueError):
                 pass
             roof = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
