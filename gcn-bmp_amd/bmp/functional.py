@@ -53,8 +53,10 @@ class EmbedFn(Function):
         (ids,) = ctx.saved_tensors
         dout = dout.contiguous()
         N, d = dout.shape
-        dW = torch.zeros(ctx.V, d, dtype=torch.float32, device=dout.device)
-        check(L.bmp_embed_bwd(ptr(ids), ptr(dout), N, d, ctx.V, ptr(dW), stream()), "bmp_embed_bwd")
+        dW = torch.empty(ctx.V, d, dtype=torch.float32, device=dout.device)
+        nws = L.bmp_embed_bwd_ws_floats(N, d, ctx.V)
+        ws = _ws(nws, dout.device)
+        check(L.bmp_embed_bwd(ptr(ids), ptr(dout), N, d, ctx.V, ptr(dW), ptr(ws), nws, stream()), "bmp_embed_bwd")
         return dW, None
 
 
@@ -371,8 +373,9 @@ class PEmbedFn(Function):
         L = _lib.lib()
         dout = dout.contiguous()
         N, d = dout.shape
-        ctx.dW.zero_()
-        check(L.bmp_embed_bwd(ptr(ctx.ids), ptr(dout), N, d, ctx.V, ptr(ctx.dW), stream()), "bmp_embed_bwd")
+        nws = L.bmp_embed_bwd_ws_floats(N, d, ctx.V)
+        ws = _ws(nws, dout.device)
+        check(L.bmp_embed_bwd(ptr(ctx.ids), ptr(dout), N, d, ctx.V, ptr(ctx.dW), ptr(ws), nws, stream()), "bmp_embed_bwd")
         return None, None, None, None
 
 

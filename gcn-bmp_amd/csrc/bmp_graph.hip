@@ -16,12 +16,13 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ ids, 
     }
 }
 
-// dW[id, :] += sum_{rows with ids[row]==id} dout[row, :].  Each workgroup accumulates its row chunk
-// in an LDS copy of the table (V x d floats), then flushes the rows it touched with one global
-// float atomic per element (most rows are carbon / pad, so per-row global atomics would pile
-// onto two table rows).
+// dW[id, :] = sum_{rows with ids[row]==id} dout[row, :], in two deterministic passes.  Pass 1: each workgroup
+// accumulates its 128-row chunk in an LDS copy of the table (V x d floats) and writes the table rows it touched,
+// plus a touched flag per id, to its own slab.  Pass 2: one workgroup per id sums that row over the slabs in a
+// fixed order.  (Most rows are carbon or padding: flushing the LDS tables with global float atomics sent ~450
+// memory-side atomic requests to each of a handful of 64-byte lines and took 45 of the kernel's 60 us.)
 __global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ ids, const float* __restrict__ dout, int N, int d,
-                                                   int V, int rows_per_block, float* dW) {
+                                                   int V, int rows_per_block, float* __restrict__ slab, int* __restrict__ flags) {
     extern __shared__ float tab[];                // V*d floats + V flags
     int* touched = (int*)(tab + (size_t)V * d);
     for (int i = threadIdx.x; i < V * d; i += 256) tab[i] = 0.f;
@@ -30,16 +31,47 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ ids, 
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = (r0 + rows_per_block) < N ? (r0 + rows_per_block) : N;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const int id = ids[row];
-        if (lane == 0) touched[id] = 1;
-        for (int c = lane; c < d; c += 64) atomicAdd(&tab[(size_t)id * d + c], dout[(size_t)row * d + c]);
+    // eight rows of a wave in flight at a time
+    for (int base = r0 + wave; base < r1; base += 32) {
+        int id8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int row = base + 4 * u; id8[u] = row < r1 ? ids[row] : -1; }
+        for (int c = lane; c < d; c += 64) {
+            float v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v8[u] = id8[u] >= 0 ? dout[(size_t)(base + 4 * u) * d + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (id8[u] >= 0) atomicAdd(&tab[(size_t)id8[u] * d + c], v8[u]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (id8[u] >= 0) touched[id8[u]] = 1;
+        }
     }
     __syncthreads();
+    float* my = slab + (size_t)blockIdx.x * V * d;
     for (int id = 0; id < V; ++id) {
         if (touched[id])
-            for (int c = threadIdx.x; c < d; c += 256) atomicAdd(&dW[(size_t)id * d + c], tab[(size_t)id * d + c]);
+            for (int c = threadIdx.x; c < d; c += 256) my[(size_t)id * d + c] = tab[(size_t)id * d + c];
     }
+    for (int id = threadIdx.x; id < V; id += 256) flags[(size_t)id * gridDim.x + blockIdx.x] = touched[id];
+}
+
+// pass 2: dW[id, c] = sum over the slabs that touched id (fixed order: four interleaved partial sums, then a tree)
+__global__ __launch_bounds__(256) void k_embed_bwd_reduce(const float* __restrict__ slab, const int* __restrict__ flags,
+                                                          int nslab, int V, int d, float* __restrict__ dW) {
+    __shared__ float red[4][64];
+    const int id = blockIdx.x;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float v = 0.f;
+    if (c < d)
+        for (int s = g; s < nslab; s += 4)
+            if (flags[(size_t)id * nslab + s]) v += slab[((size_t)s * V + id) * d + c];
+    red[g][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (g == 0 && c < d) dW[(size_t)id * d + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -129,8 +161,16 @@ extern "C" int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float
     return 0;
 }
 
-extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, hipStream_t st) {
-    BMP_REQUIRE(N > 0 && d > 0 && V > 0);
+#define EMB_ROWS_PER_BLOCK 128
+extern "C" size_t bmp_embed_bwd_ws_floats(int N, int d, int V) {
+    const size_t nb = (size_t)(N + EMB_ROWS_PER_BLOCK - 1) / EMB_ROWS_PER_BLOCK;
+    return nb * V * d + nb * V;                    // table slabs | touched flags (int32)
+}
+
+// dW [V x d] is overwritten (no zero-fill by the caller needed).
+extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, float* ws, size_t ws_floats,
+                             hipStream_t st) {
+    BMP_REQUIRE(N > 0 && d > 0 && V > 0 && ws != nullptr && ws_floats >= bmp_embed_bwd_ws_floats(N, d, V));
     const size_t lds_bytes = ((size_t)V * d + V) * sizeof(float);
     BMP_REQUIRE(lds_bytes <= 160 * 1024);
     static bool attr_set = false;
@@ -139,9 +179,12 @@ extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, in
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int rows_per_block = 128;
-    hipLaunchKernelGGL(k_embed_bwd, dim3((N + rows_per_block - 1) / rows_per_block), dim3(256), lds_bytes, st, ids, dout, N,
-                       d, V, rows_per_block, dW);
+    const int nb = (N + EMB_ROWS_PER_BLOCK - 1) / EMB_ROWS_PER_BLOCK;
+    float* slab = ws;
+    int* flags = (int*)(ws + (size_t)nb * V * d);
+    hipLaunchKernelGGL(k_embed_bwd, dim3(nb), dim3(256), lds_bytes, st, ids, dout, N, d, V, EMB_ROWS_PER_BLOCK, slab, flags);
+    BMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_embed_bwd_reduce, dim3(V, (d + 63) / 64), dim3(256), 0, st, slab, flags, nb, V, d, dW);
     BMP_LAUNCH_CHECK();
     return 0;
 }

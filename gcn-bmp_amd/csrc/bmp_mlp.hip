@@ -9,7 +9,7 @@
 #define MLP_MAXW 64         // widest hidden / output layer
 #define MLP_MAXIN 1024      // widest input
 #define MLP_FR 8            // rows per workgroup, forward
-#define MLP_BR 16           // rows per workgroup, backward
+#define MLP_BR 8            // rows per workgroup, backward
 
 struct MlpArgs {
     const float* x1; const float* x2; int d1, d2;        // input row = [x1 row | x2 row]
@@ -23,6 +23,7 @@ struct MlpArgs {
 
 __global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
     __shared__ float buf[2][MLP_FR][MLP_MAXIN];
+    extern __shared__ float wt[];                     // first-layer weights, transposed: wt[k * (no + 1) + j]
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * MLP_FR;
     const int in0 = a.dims[0];
@@ -32,6 +33,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
         float v = 0.f;
         if (row < a.B) v = k < a.d1 ? a.x1[(size_t)row * a.d1 + k] : a.x2[(size_t)row * a.d2 + (k - a.d1)];
         buf[0][r][k] = v;
+    }
+    {   // W[0] is [no x ni] row-major: read along k (coalesced), write transposed with an odd row stride
+        const int ni = a.dims[0], no = a.dims[1];
+        const float* __restrict__ W = a.W[0];
+        for (int idx = tid; idx < no * ni; idx += 256) wt[(idx % ni) * (no + 1) + idx / ni] = W[idx];
     }
     __syncthreads();
     int cur = 0;
@@ -43,9 +49,14 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
         for (int idx = tid; idx < MLP_FR * no; idx += 256) {
             const int r = idx / no, j = idx % no;
             float acc = bb ? bb[j] : 0.f;
-            const float* w = W + (size_t)j * ni;
             const float* x = buf[cur][r];
-            for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
+            if (l == 0) {
+                const float* w = wt + j;
+                for (int k = 0; k < ni; ++k) acc += x[k] * w[k * (no + 1)];
+            } else {
+                const float* w = W + (size_t)j * ni;      // <= 64 x 64: cache resident
+                for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
+            }
             if (!last) acc = acc > 0.f ? acc : 0.f;
             buf[cur ^ 1][r][j] = acc;
             if (row0 + r < a.B) a.act[l][(size_t)(row0 + r) * no + j] = acc;
@@ -96,12 +107,16 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
         const float* __restrict__ W = a.W[l];
         // weight / bias gradient partials of this workgroup's rows
         float* dW = slab + off_l[l];
-        for (int idx = tid; idx < no * ni; idx += 256) {
-            const int j = idx / ni, k = idx % ni;
-            float acc = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < MLP_BR; ++r) acc += dcur[cur][r][j] * (l == 0 ? xin[r][k] : hid[l - 1][r][k]);
-            dW[idx] = acc;
+        for (int k = tid; k < ni; k += 256) {             // thread owns input column k: its MLP_BR inputs stay in registers
+            float xk[MLP_BR];
+#pragma unroll
+            for (int r = 0; r < MLP_BR; ++r) xk[r] = l == 0 ? xin[r][k] : hid[l - 1][r][k];
+            for (int j = 0; j < no; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < MLP_BR; ++r) acc += dcur[cur][r][j] * xk[r];
+                dW[j * ni + k] = acc;
+            }
         }
         for (int j = tid; j < no; j += 256) {
             float acc = 0.f;
@@ -169,7 +184,11 @@ extern "C" int bmp_mlp_fwd(const float* x1, int d1, const float* x2, int d2, int
     MlpArgs a;
     int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, b, act);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mlp_fwd, dim3((B + MLP_FR - 1) / MLP_FR), dim3(256), 0, st, a);
+    const size_t wt_bytes = (size_t)dims[0] * (dims[1] + 1) * sizeof(float);          // <= 1024 x 65 floats
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 65536);
+    if (e != hipSuccess) return (int)e;
+    BMP_REQUIRE(wt_bytes + 65536 <= 160 * 1024);
+    hipLaunchKernelGGL(k_mlp_fwd, dim3((B + MLP_FR - 1) / MLP_FR), dim3(256), wt_bytes, st, a);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -43,7 +43,9 @@ int bmp_prof_stop(double* out);
 /* EmbedAtomID lookup -- chainer_chemistry EmbedAtomID used at models/ggnn.py:85,603
  * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:].  bwd accumulates INTO dW [V x d]. */
 int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float* out, bmp_stream_t stream);
-int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, bmp_stream_t stream);
+size_t bmp_embed_bwd_ws_floats(int N, int d, int V);
+int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, float* ws, size_t ws_floats,
+                  bmp_stream_t stream);   /* dW is overwritten; two deterministic passes through ws */
 
 /* Message function -- GGNN.update message part models/ggnn.py:215-243 (= GGNNUpdate
  * models/update/ggnn_update.py:31-50); with WsT/bs/act=TANH the whole RelGCN layer
