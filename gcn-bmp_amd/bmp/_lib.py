@@ -55,6 +55,9 @@ SIGNATURES = {
     "bmp_mlp_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "bmp_sce_fwd": (_I, [_P, _P, _I, _P, _P, _P]),
     "bmp_sce_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P]),
+    "bmp_pairfeat_cols": (_I, [_I, _I, _I]),
+    "bmp_pairfeat_fwd": (_I, [_I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "bmp_pairfeat_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bmp_gather_sum": (_I, [_P, _I, _P, _P, _I, _I, _P]),
     "bmp_adam_step": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _P]),
     "bmp_coattn_zcols": (_I, [_I, _I]),

@@ -59,8 +59,24 @@ class GraphConvPredictorForPair(nn.Module):
         return sigmoid_cross_entropy(y, t)
 
 
+def build_link_predictor(sim_method: str, fp_out_dim: int, class_num: int, net_hidden_dims=(32, 16)):
+    """The ``lp`` selection of set_up_predictor, train_binary.py:165-187."""
+    if sim_method == "mlp":
+        return MLP(class_num, net_hidden_dims, in_dim=2 * fp_out_dim)
+    from .link import NTN, DistMult, HolE, SymMLP
+    if sim_method == "ntn":
+        return NTN(left_dim=fp_out_dim, right_dim=fp_out_dim, out_dim=class_num, ntn_out_dim=8, hidden_dims=net_hidden_dims)
+    if sim_method == "symmlp":
+        return SymMLP(out_dim=class_num, hidden_dims=net_hidden_dims, fp_dim=fp_out_dim)
+    if sim_method == "hole":
+        return HolE(out_dim=class_num, hidden_dims=net_hidden_dims, fp_dim=fp_out_dim)
+    if sim_method == "dist-mult":
+        return DistMult(left_dim=fp_out_dim, right_dim=fp_out_dim, out_dim=class_num, dm_out_dim=8, hidden_dims=net_hidden_dims)
+    raise ValueError('[ERROR] Invalid link prediction model: {}'.format(sim_method))     # train_binary.py:188
+
+
 def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=True, attn: Optional[str] = "nie",
-                         head=8, class_num=1, encoder="ggnn", mlp_hidden=(32, 16)):
+                         head=8, class_num=1, encoder="ggnn", mlp_hidden=(32, 16), sim_method="mlp"):
     """set_up_predictor counterpart (train_binary.py:144-277) for the configs of BASELINE.json."""
     if encoder == "ggnn":
         enc = GGNN(out_dim=out_dim, hidden_dim=hidden_dim, n_layers=n_layers, weight_tying=weight_tying)
@@ -90,4 +106,4 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
         a = NeuralCoattention(hidden_dim=hidden_dim, out_dim=out_dim, activation="tanh")
     elif attn is not None:
         raise ValueError('[ERROR] Invalid Co-Attention Method.')
-    return GraphConvPredictorForPair(enc, a, MLP(class_num, mlp_hidden, in_dim=2 * out_dim))
+    return GraphConvPredictorForPair(enc, a, build_link_predictor(sim_method, out_dim, class_num, mlp_hidden))

@@ -180,6 +180,17 @@ int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float* x2, int d
 int bmp_sce_fwd(const float* y, const int* t, int n, float* loss, float* sums, bmp_stream_t stream);
 int bmp_sce_bwd(const float* y, const int* t, int n, const float* sums, const float* gout, float* dy, bmp_stream_t stream);
 
+/* ---- pair features of the other link predictors (models/mlp.py:48-193, train_binary.py:102-116); the relu-MLP tail is
+ * bmp_mlp_*.  kind: 0 SymMLP [g1+g2 | g1*g2] (:104-110), 1 HolE circular correlation c[k] = sum_i g1[i] g2[(i+k)%d]
+ * (:126-151), 2 DistMult y[o] = sum_p W[o,p] g1[p] g2[p] (BilinearDiag :153-193, W [K x d]), 3 NTN = links.Bilinear
+ * (:52,66: W [d1 x d2 x K], optional V1 [d1 x K], V2 [d2 x K], b [K]).  out / dout [B x bmp_pairfeat_cols]. */
+int bmp_pairfeat_cols(int kind, int d, int K);
+int bmp_pairfeat_fwd(int kind, const float* x1, const float* x2, int B, int d1, int d2, const float* W, const float* V1,
+                     const float* V2, const float* b, int K, float* out, bmp_stream_t stream);
+int bmp_pairfeat_bwd(int kind, const float* dout, const float* x1, const float* x2, int B, int d1, int d2, const float* W,
+                     const float* V1, const float* V2, int K, float* dx1, float* dx2, float* dW, float* dV1, float* dV2,
+                     float* db, bmp_stream_t stream);
+
 /* ---- host glue of a training step (no counterpart kernels in the reference: there the layout changes are Chainer
  * function nodes and the optimizer is chainer.optimizers.Adam, train_ddi_modify.py:289) ----
  * bmp_gather_sum: dst[i] (=|+=) sum_k src[idx[k*n + i]] over table entries >= 0 (idx is [K][n] int32).  One launch

@@ -369,6 +369,49 @@ def mlp_forward(p: Params, x: Tensor, n_hidden: int, prefix: str = "mlp/") -> Te
     return linear(h, p[f"{prefix}l_out/W"], p[f"{prefix}l_out/b"])
 
 
+def _mlp_tail(p: Params, h: Tensor, n_hidden: int, prefix: str, layers: str) -> Tensor:
+    for i in range(n_hidden):
+        h = torch.relu(linear(h, p[f"{prefix}{layers}/{i}/W"], p[f"{prefix}{layers}/{i}/b"]))
+    return linear(h, p[f"{prefix}l_out/W"], p[f"{prefix}l_out/b"])
+
+
+def ntn_forward(p: Params, left_x: Tensor, right_x: Tensor, n_hidden: int, prefix: str = "mlp/") -> Tensor:
+    """NTN.__call__ models/mlp.py:65-72: links.Bilinear(left, right, ntn_out_dim) (:52), relu-MLP, l_out."""
+    h = bilinear(left_x, right_x, p[prefix + "ntn_layer/W"], p[prefix + "ntn_layer/V1"], p[prefix + "ntn_layer/V2"],
+                 p[prefix + "ntn_layer/b"])
+    return _mlp_tail(p, h, n_hidden, prefix, "mlp_layers")
+
+
+def distmult_forward(p: Params, left_x: Tensor, right_x: Tensor, n_hidden: int, prefix: str = "mlp/") -> Tensor:
+    """DistMult.__call__ models/mlp.py:87-93 over BilinearDiag (:153-193): bilinear(e1, e2, W_mat) with
+    W_mat[:, :, o] = diag(W[o]) and no V1/V2/b terms (:181-182), i.e. y[o] = sum_p W[o,p] e1[p] e2[p]."""
+    W = p[prefix + "dm_layer/W"]                                   # (out, left)
+    W_mat = torch.stack([torch.diag(v) for v in W]).permute(1, 2, 0)   # (left, right, out)  :186-192
+    h = torch.einsum("ni,ijk,nj->nk", left_x, W_mat, right_x)
+    return _mlp_tail(p, h, n_hidden, prefix, "mlp_layers")
+
+
+def symmlp_forward(p: Params, left_x: Tensor, right_x: Tensor, n_hidden: int, prefix: str = "mlp/") -> Tensor:
+    """SymMLP.__call__ models/mlp.py:104-110."""
+    h = torch.cat((left_x + right_x, left_x * right_x), dim=1)
+    return _mlp_tail(p, h, n_hidden, prefix, "layers")
+
+
+def circular_correlation(left_x: Tensor, right_x: Tensor) -> Tensor:
+    """HolE.circular_correlation models/mlp.py:126-151, op for op: fft of both (zero imaginary parts),
+    conj(fft(a)) * fft(b) as real/imaginary pairs, real part of the ifft."""
+    fa = torch.fft.fft(torch.complex(left_x, torch.zeros_like(left_x)), dim=-1)
+    fb = torch.fft.fft(torch.complex(right_x, torch.zeros_like(right_x)), dim=-1)
+    prod_real = fa.real * fb.real + fa.imag * fb.imag           # :144
+    prod_imag = fa.real * fb.imag - fa.imag * fb.real           # :145
+    return torch.fft.ifft(torch.complex(prod_real, prod_imag), dim=-1).real
+
+
+def hole_forward(p: Params, left_x: Tensor, right_x: Tensor, n_hidden: int, prefix: str = "mlp/") -> Tensor:
+    """HolE.__call__ models/mlp.py:119-124."""
+    return _mlp_tail(p, circular_correlation(left_x, right_x), n_hidden, prefix, "layers")
+
+
 def sigmoid_cross_entropy(y: Tensor, t: Tensor) -> Tensor:
     """chainer.functions.sigmoid_cross_entropy(normalize=True): mean over
     elements with t != -1 of softplus(y) - t*y (train_ddi_modify.py:285)."""
@@ -533,6 +576,28 @@ def init_mlp(dr: _Draw, prefix: str, in_dim: int, out_dim: int, hidden_dims: Seq
     n = in_dim
     for i, hd in enumerate(hidden_dims):
         dr.lin(f"{prefix}layers/{i}", n, hd)
+        n = hd
+    dr.lin(f"{prefix}l_out", n, out_dim)
+
+
+def init_link(dr: _Draw, prefix: str, kind: str, fp_dim: int, out_dim: int, hidden_dims: Sequence[int] = (32, 16),
+              feat_dim: int = 8) -> None:
+    """Link predictors of models/mlp.py:48-124 (kind: ntn / distmult / symmlp / hole); ``feat_dim`` =
+    ntn_out_dim / dm_out_dim (train_binary.py:173,184)."""
+    if kind == "ntn":
+        dr.bil(prefix + "ntn_layer", fp_dim, fp_dim, feat_dim)
+        n, layers = feat_dim, "mlp_layers"
+    elif kind == "distmult":
+        dr.normal(prefix + "dm_layer/W", (feat_dim, fp_dim), 1.0 / math.sqrt(fp_dim))
+        n, layers = feat_dim, "mlp_layers"
+    elif kind == "symmlp":
+        n, layers = 2 * fp_dim, "layers"
+    elif kind == "hole":
+        n, layers = fp_dim, "layers"
+    else:
+        raise ValueError(kind)
+    for i, hd in enumerate(hidden_dims):
+        dr.lin(f"{prefix}{layers}/{i}", n, hd)
         n = hd
     dr.lin(f"{prefix}l_out", n, out_dim)
 
