@@ -1,0 +1,114 @@
+"""The headline configuration at its full size (BASELINE.json configs[1]: 1024 drug pairs of the 544-drug store,
+GGNN 4-step d=128 + Nie co-attention + MLP) checked through properties that do not need a dense oracle of that
+size, plus an oracle spot check on a handful of its pairs padded the way the full batch pads them."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B = 1024
+
+
+@pytest.fixture(scope="module")
+def world():
+    from bmp import packed, synth
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    store = synth.make_store()
+    ms = packed.MolStore(store)
+    i1, i2, lab = synth.make_pairs()
+    p = O.make_pair_params(777, hidden_dim=128, out_dim=128, n_layers=4, attn="nie", head=8, dtype=torch.float32,
+                           bias_scale=0.05)
+    model = build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, attn="nie", head=8).to(dev)
+    load_param_dict(model, p)
+    return dict(dev=dev, store=store, ms=ms, i1=i1[:B], i2=i2[:B], lab=lab[:B], p=p, model=model)
+
+
+def _logits(w, i1, i2, pad_to=None):
+    from bmp import packed
+    pb = packed.pack_from_store(w["ms"], [i1, i2], device=w["dev"], pad_to=pad_to)
+    with torch.no_grad():
+        return w["model"](pb), pb
+
+
+def test_pair_order_is_irrelevant(world):
+    """Pairs are independent units: any permutation of the batch (which re-packs every tile) gives every pair the
+    same logit up to fp32 summation order (the tile kernels rotate their K walk by the tile index)."""
+    w = world
+    y, _ = _logits(w, w["i1"], w["i2"])
+    perm = np.random.RandomState(1).permutation(B)
+    yp, _ = _logits(w, w["i1"][perm], w["i2"][perm])
+    ref = y[torch.from_numpy(perm).to(y.device)]
+    assert (yp - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0)
+    assert torch.isfinite(y).all() and y.std().item() > 1e-3
+
+
+def test_padding_affine_law_full_size(world):
+    """The reference sums the readout over padded atoms too (models/ggnn.py:340): one more pad column adds the same
+    vector (the pad atom's readout term) to every molecule of the side."""
+    from bmp import packed
+    w = world
+    n = w["ms"].n_atoms
+    A1, A2 = int(n[w["i1"]].max()), int(n[w["i2"]].max())
+    enc = w["model"].graph_conv
+    with torch.no_grad():
+        g0 = enc(packed.pack_from_store(w["ms"], [w["i1"], w["i2"]], device=w["dev"], pad_to=[A1, A2]))
+        g1 = enc(packed.pack_from_store(w["ms"], [w["i1"], w["i2"]], device=w["dev"], pad_to=[A1 + 1, A2 + 3]))
+    diff = g1 - g0
+    d1, d2 = diff[:B], diff[B:]
+    scale = g0.abs().max().item()
+    assert (d1 - d1[0]).abs().max().item() <= 1e-5 * scale
+    assert (d2 - 3.0 * d1[0]).abs().max().item() <= 1e-5 * scale          # three extra pad atoms on side 2
+    assert d1[0].abs().max().item() > 0
+
+
+def test_gradient_of_the_batch_is_the_mean_over_shards(world):
+    """KAT (viii), at full size on one GPU: with both halves padded like the whole batch, the gradient of the mean
+    loss over 1024 pairs is the mean of the two 512-pair gradients (what the data-parallel all-reduce computes)."""
+    from bmp import packed
+    w = world
+    n = w["ms"].n_atoms
+    pad = [int(n[w["i1"]].max()), int(n[w["i2"]].max())]
+    model = w["model"]
+    t = torch.from_numpy(w["lab"].reshape(-1, 1)).to(w["dev"])
+
+    def grad(sl):
+        for p in model.parameters():
+            p.grad = None
+        pb = packed.pack_from_store(w["ms"], [w["i1"][sl], w["i2"][sl]], device=w["dev"], pad_to=pad)
+        model.loss(model(pb), t[sl]).backward()
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()])
+
+    whole = grad(slice(0, B))
+    halves = 0.5 * (grad(slice(0, B // 2)) + grad(slice(B // 2, B)))
+    scale = whole.abs().max().item()
+    assert (whole - halves).abs().max().item() <= 2e-5 * scale
+
+
+def test_oracle_spot_check_inside_the_full_batch(world):
+    """Six pairs of the 1024, through the dense CPU oracle with the full batch's padding, against their logits in
+    the full-batch GPU run (1e-4 relative, the north star's fp32 tolerance)."""
+    from oracle import ref_cpu as O
+    w = world
+    y, _ = _logits(w, w["i1"], w["i2"])
+    n = w["ms"].n_atoms
+    A1, A2 = int(n[w["i1"]].max()), int(n[w["i2"]].max())
+    pick = np.random.RandomState(3).choice(B, 6, replace=False)
+
+    def dense(idx, A):
+        atoms = np.zeros((len(idx), A), np.int32); adj = np.zeros((len(idx), 4, A, A), np.float32)
+        for b, k in enumerate(idx):
+            m = w["store"][k]
+            atoms[b, :m.n] = m.atoms; adj[b, :, :m.n, :m.n] = m.dense_adj()
+        return torch.from_numpy(atoms), torch.from_numpy(adj)
+
+    a1, j1 = dense(w["i1"][pick], A1)
+    a2, j2 = dense(w["i2"][pick], A2)
+    p64 = {k: v.double() for k, v in w["p"].items()}
+    yo, _, _ = O.pair_forward(p64, a1, j1.double(), a2, j2.double(), n_layers=4, attn="nie")
+    got = y[torch.from_numpy(pick).to(y.device)].double().cpu()
+    scale = max(yo.abs().max().item(), 1.0)
+    assert (got - yo).abs().max().item() <= 1e-4 * scale
