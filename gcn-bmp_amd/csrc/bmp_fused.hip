@@ -43,9 +43,24 @@ struct StepArgs {
 //   Bp[nb]  = B_nb + 4 * (lane >> 5) * ldw[nb] + col      (col = this lane's output column)
 // `rot` (multiple of 8, < K) rotates the K loop: workgroups walk the shared weight matrices from different
 // starting rows, so the 256 CUs do not all request the same L2 lines at the same moment.
+// The first two B fragments of a tile_mma call, requested early: every call otherwise opens with an L2 round trip
+// during which the matrix pipe has nothing to do (7-8 calls per tile).  The caller issues the prefetch before the
+// gather / epilogue / group barrier that precedes the call.
+template <int NB>
+struct BPre { f32x4 b0[NB], b1[NB]; };
+template <int NB>
+__device__ __forceinline__ void tile_b_prefetch(BPre<NB>& p, const float* const (&Bp)[NB], const int (&ldw)[NB], int K, int rot) {
+    int k1 = rot + 8; if (k1 >= K) k1 -= K;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        p.b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)rot * ldw[nb]);
+        p.b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
+    }
+}
+
 template <int NB, int RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot) {
+                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
     // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
     // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
     // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
@@ -54,8 +69,11 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
     int k1 = k + 8; if (k1 >= K) k1 -= K;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)k * ldw[nb]);
-        b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
+        if (pre) { b0[nb] = pre->b0[nb]; b1[nb] = pre->b1[nb]; }
+        else {
+            b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)k * ldw[nb]);
+            b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
+        }
     }
     f32x4 a0[RB], a1[RB];            // A fragments (LDS) run one k-step ahead
 #pragma unroll
@@ -261,6 +279,10 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     f32x16 acc_m[1][RB];
     zero_acc(acc_m[0]);
     for (int e = 0; e < 4; ++e) {
+        const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
+        const int ldw[1] = {D};
+        BPre<1> pre;
+        tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
         float wd;
         FZ_GATHER(Hs, As, e, &wd);
         if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
@@ -268,13 +290,21 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) {
-            const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
-            const int ldw[1] = {D};
-            tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot);
-        }
+        if (any) tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
+    // first B fragments of the h-part of the gates: requested now, used after the m epilogue and its barrier
+    constexpr int NG = FIRST ? 2 : 3;                     // gates computed: first call after reset z and c only
+    int ldwg[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ldwg[g] = 3 * D;
+    const float* const base_h = a.AT + (size_t)(4 * hi) * 3 * D + 4 * col + (FIRST ? 4 * D : 0);
+    const float* const base_m = a.AT + (size_t)(D + 4 * hi) * 3 * D + 4 * col + (FIRST ? 4 * D : 0);
+    const float* Bh[NG]; const float* Bm[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { Bh[g] = base_h + 4 * D * g; Bm[g] = base_m + 4 * D * g; }
+    BPre<NG> pre_h;
+    tile_b_prefetch<NG>(pre_h, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot);
     // m -> LDS (A operand of the gates) and HBM (saved for the backward)
     {
         const AccBuf mo = acc_buf<D>(a.m, row0, lrow, col);
@@ -295,25 +325,17 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     f32x16 acc_g[3][RB];
     zero_acc(acc_g[0]); zero_acc(acc_g[1]); zero_acc(acc_g[2]);
     {
-        const int ldw3[3] = {3 * D, 3 * D, 3 * D};
-        const float* base_h = a.AT + (size_t)(4 * hi) * 3 * D + 4 * col;
-        const float* base_m = a.AT + (size_t)(D + 4 * hi) * 3 * D + 4 * col;
-        if (FIRST) {      // first call after reset: z and c only, no state terms
-            f32x16 g2[2][RB];
-            zero_acc(g2[0]); zero_acc(g2[1]);
-            const int ldw2[2] = {3 * D, 3 * D};
-            const float* const Bh[2] = {base_h + 4 * D, base_h + 8 * D};
-            const float* const Bm[2] = {base_m + 4 * D, base_m + 8 * D};
-            tile_mma<2, RB>(g2, Hw, LD, Bh, ldw2, D, rot);
-            tile_mma<2, RB>(g2, Aw, LD, Bm, ldw2, D, rot);
+        f32x16 gg[NG][RB];
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) { acc_g[1][rb] = g2[0][rb]; acc_g[2][rb] = g2[1][rb]; }
-        } else {
-            const float* const Bh[3] = {base_h, base_h + 4 * D, base_h + 8 * D};
-            const float* const Bm[3] = {base_m, base_m + 4 * D, base_m + 8 * D};
-            tile_mma<3, RB>(acc_g, Hw, LD, Bh, ldw3, D, rot);
-            tile_mma<3, RB>(acc_g, Aw, LD, Bm, ldw3, D, rot);
-        }
+        for (int g = 0; g < NG; ++g) zero_acc(gg[g]);
+        BPre<NG> pre_m;                                   // in flight under the h-part
+        tile_b_prefetch<NG>(pre_m, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot);
+        tile_mma<NG, RB>(gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h);
+        tile_mma<NG, RB>(gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc_g[g + (FIRST ? 1 : 0)][rb] = gg[g][rb];
     }
     const float br = a.b[col], bz = a.b[D + col], bcn = a.b[2 * D + col];
     {   // r, z in place; save them
@@ -330,15 +352,17 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         }
     }
     if (!FIRST) {
+        const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
+        const int ldu[1] = {D};
+        BPre<1> pre_u;
+        tile_b_prefetch<1>(pre_u, Bu, ldu, D, rot);
         FZ_GSYNC();                          // every wave of this half is done reading M
         FZ_FOR_ACC { Al[LOFF(rb, reg)] = acc_g[0][rb][reg] * Hl[LOFF(rb, reg)]; }      // r * h
         FZ_GSYNC();
         f32x16 gc[1][RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
-        const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
-        const int ldu[1] = {D};
-        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot);
+        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot, &pre_u);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
     }
@@ -435,18 +459,18 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
             if (first) rm_st<D, 7 * D>(b_o, v, (f32x4){0.f, 0.f, 0.f, 0.f}, 4 * D);       // da_r = 0
         }
     }
-    __syncthreads();                         // whole workgroup: the staged CSR and the counters are visible
-
-    f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
-    zero_acc(acc_x[0]); zero_acc(acc_x[1]);
     const float* const Ac_h = a.A + (size_t)(2 * D + 4 * hi) * 2 * D + 4 * col;
     const float* const Az_h = a.A + (size_t)(D + 4 * hi) * 2 * D + 4 * col;
     const float* const Ar_h = a.A + (size_t)(4 * hi) * 2 * D + 4 * col;
     const int ld2[2] = {2 * D, 2 * D};
-    {   // [dh | dm] += da_c . A_c
-        const float* const Bc[2] = {Ac_h, Ac_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot);
-    }
+    const float* const Bc[2] = {Ac_h, Ac_h + 4 * D};
+    BPre<2> pre_c;
+    tile_b_prefetch<2>(pre_c, Bc, ld2, D, rot);
+    __syncthreads();                         // whole workgroup: the staged CSR and the counters are visible
+
+    f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
+    zero_acc(acc_x[0]); zero_acc(acc_x[1]);
+    tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c);       // [dh | dm] += da_c . A_c
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
         zero_acc(acc_d[0]);
@@ -491,6 +515,10 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc_h[0][rb] = acc_x[0][rb];
     for (int e = 0; e < 4; ++e) {
+        const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
+        const int ldw[1] = {4 * D};
+        BPre<1> pre;
+        tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
         float wd;
         FZ_GATHER(Xs, Ys, e, &wd);
         {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
@@ -503,11 +531,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) {
-            const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
-            const int ldw[1] = {4 * D};
-            tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot);
-        }
+        if (any) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
     // ---- dh = (MFMA part, via Y) + ex ----

@@ -1,0 +1,288 @@
+// Stand-alone anatomy of the weight-gradient GEMM (k_wgrad_lds of gcn-bmp_amd/csrc/bmp_gemm.hip): the same staging
+// loop with parts switched off, timed with HIP events.   hipcc --offload-arch=gfx950 -O3 -I gcn-bmp_amd/csrc
+// tools/wgrad_bench.hip -o tools/wgrad_bench && tools/wgrad_bench [N] [Nn]
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "bmp_common.h"
+
+#define WG_LD 132
+struct WGKArgs { const float* X; const float* dY; int ldx, ldy, K, Nn, N, rows_per_split; float* slab; };
+
+// MODE bits: 1 = no MFMA, 2 = no global loads, 4 = no LDS traffic (fragments stay constant)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_wg(WGKArgs a) {
+    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
+    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int j_tile = blockIdx.y * 128;
+    const int s = blockIdx.z;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) >> 5;
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int colx = 4 * c4, coly = j_tile + 4 * c4;
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    f32x4 xr[4], yr[4];
+    for (int i = 0; i < 4; ++i) { xr[i] = (f32x4){1.f, 2.f, 3.f, 4.f}; yr[i] = (f32x4){.5f, .25f, .125f, 1.f}; }
+#define WG_LOAD(st)                                                                              \
+    if (!(MODE & 2)) {                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+            const size_t row = (size_t)(r_begin + (st) * 32 + rr + 8 * i);                       \
+            xr[i] = *(const f32x4*)(a.X + row * a.ldx + colx);                                   \
+            yr[i] = *(const f32x4*)(a.dY + row * a.ldy + coly);                                  \
+        }                                                                                        \
+    }
+#define WG_STORE(buf)                                                                            \
+    if (!(MODE & 4)) {                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+            *(f32x4*)(&XS[buf][rr + 8 * i][4 * c4]) = xr[i];                                     \
+            *(f32x4*)(&YS[buf][rr + 8 * i][4 * c4]) = yr[i];                                     \
+        }                                                                                        \
+    }
+    if (nst > 0) { WG_LOAD(0) WG_STORE(0) }
+    __syncthreads();
+    float keep = 0.f;
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) { WG_LOAD(st + 1) }
+        float av[2][2][4], bv[2][2][4];
+#define WG_FRAG(slot, k0)                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
+            av[slot][m][t] = (MODE & 4) ? xr[m][t] : XS[buf][(k0) + 4 * hi + t][wm * 64 + m * 32 + l31]; \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                              \
+            bv[slot][n][t] = (MODE & 4) ? yr[n][t] : YS[buf][(k0) + 4 * hi + t][wn * 64 + n * 32 + l31]; \
+    }
+        WG_FRAG(0, 0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 4) { WG_FRAG(cur ^ 1, (ks + 1) * 8) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(MODE & 1)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t], bv[cur][n][t], acc[m][n]);
+            } else {
+                for (int t = 0; t < 4; ++t) keep += av[cur][0][t] + bv[cur][1][t] + av[cur][1][t] + bv[cur][0][t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st + 1 < nst) { WG_STORE(buf ^ 1) }
+        if ((MODE & 4) && (MODE & 2) == 0) keep += xr[0][0] + yr[3][3] + xr[3][1] + yr[0][2] + xr[1][0] + xr[2][0] + yr[1][0] + yr[2][0];
+        __syncthreads();
+    }
+    float* slab = a.slab + (size_t)s * a.K * a.Nn;
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = wm * 64 + m * 32 + bmp_acc_row(reg, lane);
+                slab[(size_t)i * a.Nn + j] = acc[m][n][reg] + keep;
+            }
+        }
+}
+
+
+// variant: two stages of global loads in flight (register ring), otherwise as k_wg<0>
+__global__ __launch_bounds__(256) void k_wg_ring(WGKArgs a) {
+    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
+    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int j_tile = blockIdx.y * 128;
+    const int s = blockIdx.z;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) >> 5;
+    const int c4 = tid & 31, rr = tid >> 5;
+    const int colx = 4 * c4, coly = j_tile + 4 * c4;
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    f32x4 xa[4], ya[4], xb[4], yb[4];
+#define RLOAD(xr, yr, st)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+        const size_t row = (size_t)(r_begin + (st) * 32 + rr + 8 * i);                           \
+        xr[i] = *(const f32x4*)(a.X + row * a.ldx + colx);                                       \
+        yr[i] = *(const f32x4*)(a.dY + row * a.ldy + coly);                                      \
+    }
+#define RSTORE(xr, yr, buf)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+        *(f32x4*)(&XS[buf][rr + 8 * i][4 * c4]) = xr[i];                                         \
+        *(f32x4*)(&YS[buf][rr + 8 * i][4 * c4]) = yr[i];                                         \
+    }
+#define RCOMPUTE(buf)                                                                              \
+    {                                                                                              \
+        float av[2][2][4], bv[2][2][4];                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                         \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m) av[0][m][t] = XS[buf][ks * 8 + 4 * hi + t][wm * 64 + m * 32 + l31]; \
+                _Pragma("unroll") for (int n = 0; n < 2; ++n) bv[0][n][t] = YS[buf][ks * 8 + 4 * hi + t][wn * 64 + n * 32 + l31]; \
+            }                                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                          \
+                _Pragma("unroll") for (int m = 0; m < 2; ++m)                                      \
+                    _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[0][m][t], bv[0][n][t], acc[m][n]); \
+        }                                                                                          \
+    }
+    if (nst > 0) { RLOAD(xa, ya, 0) RSTORE(xa, ya, 0) }
+    if (nst > 1) { RLOAD(xa, ya, 1) }
+    __syncthreads();
+    for (int st = 0; st < nst; st += 2) {
+        if (st + 2 < nst) { RLOAD(xb, yb, st + 2) }
+        RCOMPUTE(0)
+        if (st + 1 < nst) { RSTORE(xa, ya, 1) }
+        __syncthreads();
+        if (st + 1 >= nst) break;
+        if (st + 3 < nst) { RLOAD(xa, ya, st + 3) }
+        RCOMPUTE(1)
+        if (st + 2 < nst) { RSTORE(xb, yb, 0) }
+        __syncthreads();
+    }
+    float* slab = a.slab + (size_t)s * a.K * a.Nn;
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+            for (int reg = 0; reg < 16; ++reg) slab[(size_t)(wm * 64 + m * 32 + bmp_acc_row(reg, lane)) * a.Nn + j] = acc[m][n][reg];
+        }
+}
+
+// variant: 128 x 256 output tile per workgroup, 512 threads (2 x 4 waves of 64 x 64), one workgroup per CU
+#define WY_LD 260
+__global__ __launch_bounds__(512) void k_wg_wide(WGKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float (*XS)[32][WG_LD] = (float (*)[32][WG_LD])sm;
+    float (*YS)[32][WY_LD] = (float (*)[32][WY_LD])(sm + 2 * 32 * WG_LD);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int j_tile = blockIdx.y * 256;
+    const int s = blockIdx.z;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) >> 5;
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    // X stage 32 x 128 = 1024 float4 -> 2 per thread; Y stage 32 x 256 = 2048 float4 -> 4 per thread
+    f32x4 xr[2], yr[4];
+    const int xc4 = tid & 31, xrr = tid >> 5;       // 16 row groups
+    const int yc4 = tid & 63, yrr = tid >> 6;       // 8 row groups
+    const bool oky = j_tile + 4 * yc4 < a.Nn;
+#define WLOAD(st)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) xr[i] = *(const f32x4*)(a.X + (size_t)(r_begin + (st) * 32 + xrr + 16 * i) * a.ldx + 4 * xc4); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) yr[i] = oky ? *(const f32x4*)(a.dY + (size_t)(r_begin + (st) * 32 + yrr + 8 * i) * a.ldy + j_tile + 4 * yc4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#define WSTORE(buf)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) *(f32x4*)(&XS[buf][xrr + 16 * i][4 * xc4]) = xr[i]; \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) *(f32x4*)(&YS[buf][yrr + 8 * i][4 * yc4]) = yr[i];
+    if (nst > 0) { WLOAD(0) WSTORE(0) }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) { WLOAD(st + 1) }
+        float av[2][2][4], bv[2][2][4];
+#define WFRAG(slot, k0)                                                                            \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) av[slot][m][t] = XS[buf][(k0) + 4 * hi + t][wm * 64 + m * 32 + l31]; \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) bv[slot][n][t] = YS[buf][(k0) + 4 * hi + t][wn * 64 + n * 32 + l31]; \
+    }
+        WFRAG(0, 0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 4) { WFRAG(cur ^ 1, (ks + 1) * 8) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t], bv[cur][n][t], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st + 1 < nst) { WSTORE(buf ^ 1) }
+        __syncthreads();
+    }
+    float* slab = a.slab + (size_t)s * a.K * a.Nn;
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+            if (j < a.Nn)
+                for (int reg = 0; reg < 16; ++reg) slab[(size_t)(wm * 64 + m * 32 + bmp_acc_row(reg, lane)) * a.Nn + j] = acc[m][n][reg];
+        }
+}
+
+static float run_k(void (*launch)(const WGKArgs&, int, int), const WGKArgs& a, int tiles, int S, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch(a, tiles, S);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) launch(a, tiles, S);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return 1e3f * ms / reps;
+}
+static void launch_ring(const WGKArgs& a, int tiles, int S) { hipLaunchKernelGGL(k_wg_ring, dim3(1, tiles, S), dim3(256), 0, 0, a); }
+static void launch_wide(const WGKArgs& a, int tiles, int S) {
+    const size_t lds = (size_t)2 * 32 * (WG_LD + WY_LD) * 4;
+    hipFuncSetAttribute((const void*)k_wg_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_wg_wide, dim3(1, (a.Nn + 255) / 256, S), dim3(512), lds, 0, a);
+}
+
+template <int MODE>
+static float run(const WGKArgs& a, int tiles, int S, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_wg<MODE>), dim3(1, tiles, S), dim3(256), 0, 0, a);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_wg<MODE>), dim3(1, tiles, S), dim3(256), 0, 0, a);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return 1e3f * ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 58240, Nn = argc > 2 ? atoi(argv[2]) : 896, K = 128;
+    const int tiles = Nn / 128;
+    float *X, *dY, *slab;
+    hipMalloc(&X, (size_t)N * K * 4); hipMalloc(&dY, (size_t)N * Nn * 4);
+    std::vector<float> h((size_t)N * Nn);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(dY, h.data(), (size_t)N * Nn * 4, hipMemcpyHostToDevice);
+    hipMemcpy(X, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    const int splits[] = {512 / tiles, 256 / tiles, 1024 / tiles};
+    for (int si = 0; si < 3; ++si) {
+        int S = splits[si];
+        int rps = ((N + S - 1) / S + 31) & ~31;
+        S = (N + rps - 1) / rps;
+        hipMalloc(&slab, (size_t)S * K * Nn * 4);
+        WGKArgs a{X, dY, K, Nn, K, Nn, N, rps, slab};
+        const double gf = 2.0 * N * K * (double)Nn / 1e9;
+        printf("N %d Nn %d tiles %d S %d rows/split %d  (%.1f GFLOP, ideal %.1f us at 157.3 TF)\n", N, Nn, tiles, S, rps, gf, gf / 157.3e3 * 1e6);
+        printf("  full            %7.1f us\n", run<0>(a, tiles, S, 20));
+        printf("  no MFMA         %7.1f us\n", run<1>(a, tiles, S, 20));
+        printf("  no global loads %7.1f us\n", run<2>(a, tiles, S, 20));
+        printf("  no LDS          %7.1f us\n", run<4>(a, tiles, S, 20));
+        printf("  MFMA only       %7.1f us\n", run<6>(a, tiles, S, 20));
+        printf("  loads only      %7.1f us\n", run<5>(a, tiles, S, 20));
+        printf("  ring (2 stages) %7.1f us\n", run_k(launch_ring, a, tiles, S, 20));
+        {
+            const int wt = (Nn + 255) / 256;
+            int Sw = 256 / wt; int rw = ((N + Sw - 1) / Sw + 31) & ~31; Sw = (N + rw - 1) / rw;
+            WGKArgs b = a; b.rows_per_split = rw;
+            if ((size_t)Sw <= (size_t)S) printf("  wide 128x256 (S %d) %7.1f us\n", Sw, run_k(launch_wide, b, wt, Sw, 20));
+        }
+        hipFree(slab);
+    }
+    return 0;
+}
