@@ -147,7 +147,12 @@ class PNieFn(Function):
         dev = X1.device
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         ZC = L.bmp_coattn_zcols(o, H)
-        X1 = X1.contiguous(); X2 = X2.contiguous()
+        ctx.joint = X2 is None          # one row tensor for both sides: its gradient comes back as ONE tensor too
+        if ctx.joint:                   # (two slices would cost autograd two zero-fills, two copies and an add)
+            rows = X1.contiguous()
+            X1, X2 = rows[:T1 * _lib.lib().bmp_tile_rows()], rows[T1 * _lib.lib().bmp_tile_rows():]
+        else:
+            X1 = X1.contiguous(); X2 = X2.contiguous()
         N1, N2 = X1.shape[0], X2.shape[0]
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         Q2, Z1, Z2 = f(N2, d), f(N1, ZC), f(N2, ZC)
@@ -171,7 +176,11 @@ class PNieFn(Function):
         d, o, H, act, ZC, mode = ctx.dims
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         dout1, dout2 = dout1.contiguous(), dout2.contiguous()
-        dX1, dX2 = torch.empty_like(X1), torch.empty_like(X2)
+        if ctx.joint:
+            dX = torch.empty(X1.shape[0] + X2.shape[0], d, dtype=torch.float32, device=X1.device)
+            dX1, dX2 = dX[:X1.shape[0]], dX[X1.shape[0]:]
+        else:
+            dX1, dX2 = torch.empty_like(X1), torch.empty_like(X2)
         nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
         ws = _ws(nws, X1.device)
         check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1),
@@ -181,6 +190,8 @@ class PNieFn(Function):
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(G["dWbT"]), ptr(G["dZW1T"]), ptr(G["dZW2T"]), ptr(G["dzb"]), ptr(G["dwa"]),
                                    ptr(ws), nws, stream()), "bmp_coattn_nie_bwd")
+        if ctx.joint:
+            return dX, None, None, None, None, None, None, None, None, None, None, None
         return dX1, dX2, None, None, None, None, None, None, None, None, None, None
 
 
@@ -211,7 +222,9 @@ class _FinePlanMixin:
 
     def _forward_fast(self, atoms_1, atoms_2, fast, mode):
         P, G, _state, _tape = fast
-        X1, X2, w1, w2, meta, _joint = pair_rows(atoms_1, atoms_2)
+        X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
+        if joint:
+            X1, X2 = atoms_1.rows, None
         return PNieFn.apply(X1, X2, P, G, w1, w2, meta, self.hidden_dim, self.out_dim, self._heads(),
                             ACT[self.activation], mode)
 

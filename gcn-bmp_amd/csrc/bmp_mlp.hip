@@ -150,10 +150,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
 // through pointer/offset pairs
 struct MlpRedArgs { const float* slab; int nslab, stride; float* dW[MLP_MAXL]; float* db[MLP_MAXL]; int off[MLP_MAXL + 1]; int nw[MLP_MAXL]; int nl; };
 __global__ __launch_bounds__(256) void k_mlp_reduce(MlpRedArgs a) {
+    __shared__ float red[4][64];
     const int total = a.off[a.nl];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < a.nslab; ++s) v += a.slab[(size_t)s * a.stride + i];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
+    float v = 0.f;
+    if (i < total)
+        for (int s = g; s < a.nslab; s += 4) v += a.slab[(size_t)s * a.stride + i];      // four interleaved partial sums
+    red[g][c] = v;
+    __syncthreads();
+    if (g == 0 && i < total) {
+        v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
         int l = 0;
         while (l + 1 < a.nl && i >= a.off[l + 1]) ++l;
         const int loc = i - a.off[l];
@@ -219,7 +226,7 @@ extern "C" int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float
     a.dy = dy; a.dx1 = dx1; a.dx2 = dx2; a.slab = ws; a.slab_stride = off;
     hipLaunchKernelGGL(k_mlp_bwd, dim3(nwg), dim3(256), 0, st, a);
     BMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 255) / 256), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 63) / 64), dim3(256), 0, st, r);
     BMP_LAUNCH_CHECK();
     return 0;
 }
