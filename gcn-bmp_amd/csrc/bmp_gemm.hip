@@ -194,6 +194,7 @@ struct WGKArgs {
     const float* dY; int ldy;
     int K, Nn, N, rows_per_split;
     float* slab;
+    const int* onehot;      // if set, X is not read: X[row, k] = (onehot[row] == k)  (embedding gradient as a GEMM)
 };
 
 template <int MB, int NB>
@@ -325,8 +326,13 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
 #define WG_LOAD(st)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
         const size_t row = (size_t)(r_begin + (st) * 32 + rr + 8 * i);                               \
-        xr[i] = okx ? *(const f32x4*)(a.X + row * a.ldx + colx) : zero4;                              \
-        if (HAS_X2 && okx) xr[i] *= *(const f32x4*)(a.X2 + row * a.ldx2 + colx);                     \
+        if (a.onehot) {                                                                              \
+            const int id = a.onehot[row] - colx;                                                     \
+            xr[i] = (f32x4){id == 0 ? 1.f : 0.f, id == 1 ? 1.f : 0.f, id == 2 ? 1.f : 0.f, id == 3 ? 1.f : 0.f}; \
+        } else {                                                                                     \
+            xr[i] = okx ? *(const f32x4*)(a.X + row * a.ldx + colx) : zero4;                          \
+            if (HAS_X2 && okx) xr[i] *= *(const f32x4*)(a.X2 + row * a.ldx2 + colx);                 \
+        }                                                                                            \
         yr[i] = oky ? *(const f32x4*)(a.dY + row * a.ldy + coly) : zero4;                             \
     }
 #define WG_STORE(buf)                                                                                \
@@ -415,6 +421,7 @@ static void wgrad_plan(int N, int K, int Nn, int& mb, int& nb, int& S, int& rps)
 }
 
 static bool wgrad_use_lds(const WGArgs& a) {
+    if (a.onehot) return (a.Nn & 3) == 0 && (a.ldy & 3) == 0 && (a.N & 31) == 0 && ((uintptr_t)a.dY & 15) == 0;
     return a.K >= 64 && a.Nn >= 64 && (a.K & 3) == 0 && (a.Nn & 3) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 &&
            (a.N & 31) == 0 && ((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.dY & 15) == 0 &&
            (!a.X2 || ((a.ldx2 & 3) == 0 && ((uintptr_t)a.X2 & 15) == 0));
@@ -451,7 +458,7 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
         int S, rps;
         wgrad_lds_plan(a.N, a.K, a.Nn, S, rps);
         const int want_cs = a.cs != nullptr;
-        WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws};
+        WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws, a.onehot};
         dim3 grid((a.K + 127) / 128, (a.Nn + 127) / 128, S);
         {
             BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st);
@@ -470,7 +477,8 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     }
     int mb, nb, S, rps;
     wgrad_plan(a.N, a.K, a.Nn, mb, nb, S, rps);
-    WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws};
+    BMP_REQUIRE(a.onehot == nullptr);        // the one-hot form exists in the LDS-staged kernel only
+    WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws, nullptr};
     dim3 grid((a.K + 64 * mb - 1) / (64 * mb), (a.Nn + 64 * nb - 1) / (64 * nb), S);
     {
     BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st);

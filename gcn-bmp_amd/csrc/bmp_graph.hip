@@ -162,15 +162,27 @@ extern "C" int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float
 }
 
 #define EMB_ROWS_PER_BLOCK 128
-extern "C" size_t bmp_embed_bwd_ws_floats(int N, int d, int V) {
+static size_t emb_table_ws_floats(int N, int d, int V) {
     const size_t nb = (size_t)(N + EMB_ROWS_PER_BLOCK - 1) / EMB_ROWS_PER_BLOCK;
     return nb * V * d + nb * V;                    // table slabs | touched flags (int32)
 }
 
-// dW [V x d] is overwritten (no zero-fill by the caller needed).
+extern "C" size_t bmp_embed_bwd_ws_floats(int N, int d, int V) {
+    const size_t a = bmp_wgrad_ws_floats(N, (V + 3) & ~3, d), b = emb_table_ws_floats(N, d, V);
+    return a > b ? a : b;
+}
+
+// dW[id, :] = sum_{rows with ids[row]==id} dout[row, :] = OneHot(ids)^T . dout: the weight-gradient GEMM with the
+// one-hot operand generated in its staging loop (nothing but dout is read; MFMA sums in a fixed order, no atomics).
+// dW [V x d] is overwritten.  Row counts that are not a multiple of 32 (never the case for packed row tensors)
+// take the two-pass LDS-table kernels above.
 extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, float* ws, size_t ws_floats,
                              hipStream_t st) {
-    BMP_REQUIRE(N > 0 && d > 0 && V > 0 && ws != nullptr && ws_floats >= bmp_embed_bwd_ws_floats(N, d, V));
+    BMP_REQUIRE(N > 0 && d > 0 && V > 0 && ids && dout && dW && ws != nullptr && ws_floats >= bmp_embed_bwd_ws_floats(N, d, V));
+    if ((N & 31) == 0 && (d & 3) == 0 && ((uintptr_t)dout & 15) == 0) {
+        WGArgs g{nullptr, nullptr, 0, 0, dout, d, V, d, N, dW, d, 0, nullptr, 0, ids};
+        return bmp_launch_wgrad(g, ws, st);
+    }
     const size_t lds_bytes = ((size_t)V * d + V) * sizeof(float);
     BMP_REQUIRE(lds_bytes <= 160 * 1024);
     static bool attr_set = false;

@@ -59,6 +59,7 @@ struct WGArgs {
     int accumulate;
     float* cs;                       // optional [Nn]: column sums of dY (bias gradient), same accumulate flag
     int cs_accumulate;               // ... or accumulated regardless of `accumulate` when != 0
+    const int* onehot;               // optional [N]: X is not read, X[row, k] = (onehot[row] == k)
 };
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
