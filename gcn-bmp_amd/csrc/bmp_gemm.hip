@@ -48,15 +48,16 @@ template <int WR, int RB, int CBW, int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
     constexpr int WC = 4 / WR;
     constexpr int NT = WC * CBW * 32;
-    static_assert(WR * RB * 32 == BMP_R, "tile must be 128 rows");
-    __shared__ __attribute__((aligned(16))) float lds[BMP_R * BMP_LDS_LD];
+    constexpr int R = WR * RB * 32;                     // rows per workgroup: 128, or 64 for the small problems
+    static_assert(R == BMP_R || R == BMP_R / 2, "a workgroup takes a whole or half a 128-row tile");
+    __shared__ __attribute__((aligned(16))) float lds[R * BMP_LDS_LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int wr = w / WC, wc = w % WC;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * BMP_R;
+    const int row0 = blockIdx.x * R;
     const int n0 = blockIdx.y * NT;
 
     f32x16 acc[RB][CBW];
@@ -74,30 +75,49 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
         colc[cb] = col < a.Nout ? col : a.Nout - 1;     // clamp loads, mask stores
     }
 
+    // The K axis of all sources as one sequence of <= 64-wide chunks.  The rows of chunk i+1 are requested into
+    // registers before the MFMAs of chunk i (they used to be loaded, waited for and stored between two barriers
+    // with the matrix pipe idle: 910 workgroups of the readout GEMM doing that in step ran at 1.3 TB/s).
+    constexpr int NLD = (R * 16) / 256;                // float4 per thread and chunk
+    f32x4 stage[NLD];
+    int cs = 0, ck0 = 0;                               // chunk being prefetched: source, k offset
+    auto load_chunk = [&](int s_, int k0_) {
+        const float* __restrict__ X = a.s[s_].X;
+        const float* __restrict__ X2 = a.s[s_].X2;
+        const int ldx = a.s[s_].ldx, ldx2 = a.s[s_].ldx2, K = a.s[s_].K;
+        const int kc4 = ((K - k0_) < 64 ? (K - k0_) : 64) >> 2;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = tid + it * 256;
+            const int r = idx >> 4, c4 = idx & 15;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c4 < kc4) {
+                v = *(const f32x4*)(X + (size_t)(row0 + r) * ldx + k0_ + 4 * c4);
+                if (X2) v *= *(const f32x4*)(X2 + (size_t)(row0 + r) * ldx2 + k0_ + 4 * c4);
+            }
+            stage[it] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int idx = tid + it * 256;
+            *(f32x4*)(&lds[(idx >> 4) * BMP_LDS_LD + 4 * (idx & 15)]) = stage[it];
+        }
+    };
+    load_chunk(0, 0);
+    store_chunk();
+    __syncthreads();
     for (int s = 0; s < a.nsrc; ++s) {
-        const float* __restrict__ X = a.s[s].X;
-        const float* __restrict__ X2 = a.s[s].X2;
         const float* __restrict__ Wt = a.s[s].Wt;
-        const int ldx = a.s[s].ldx, ldx2 = a.s[s].ldx2, ldw = a.s[s].ldw, K = a.s[s].K;
+        const int ldw = a.s[s].ldw, K = a.s[s].K;
         for (int k0 = 0; k0 < K; k0 += 64) {
             const int kc = (K - k0) < 64 ? (K - k0) : 64;
-            const int kc4 = kc >> 2;
-            __syncthreads();
-            // stage rows [row0, row0+128) x k [k0, k0+kc) : 16 float4 slots per row
-#pragma unroll
-            for (int it = 0; it < (BMP_R * 16) / 256; ++it) {
-                const int idx = tid + it * 256;
-                const int r = idx >> 4, c4 = idx & 15;
-                if (c4 < kc4) {
-                    f32x4 v = *(const f32x4*)(X + (size_t)(row0 + r) * ldx + k0 + 4 * c4);
-                    if (X2) {
-                        f32x4 u = *(const f32x4*)(X2 + (size_t)(row0 + r) * ldx2 + k0 + 4 * c4);
-                        v *= u;
-                    }
-                    *(f32x4*)(&lds[r * BMP_LDS_LD + 4 * c4]) = v;
-                }
-            }
-            __syncthreads();
+            // next chunk (possibly the first of the next source)
+            cs = s; ck0 = k0 + 64;
+            if (ck0 >= K) { cs = s + 1; ck0 = 0; }
+            const bool more = cs < a.nsrc;
+            if (more) load_chunk(cs, ck0);
             const float* wp = Wt + (size_t)(k0 + 4 * hi) * ldw;
             // operands of k-step s+1 (weights from L2, row fragments from LDS) are requested before the MFMAs
             // of step s issue; scheduling barriers keep the compiler from sinking the loads behind them
@@ -134,6 +154,11 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) b0[cb][t] = b1[cb][t];
             }
+            if (more) {
+                __syncthreads();               // every wave is done with the chunk in LDS
+                store_chunk();
+                __syncthreads();
+            }
         }
     }
 
@@ -159,7 +184,11 @@ static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
     } else if (a.Nout <= 64) {
         hipLaunchKernelGGL((k_rowgemm<2, 2, 1, EPI>), dim3(n_tiles, 1), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((k_rowgemm<1, 4, 1, EPI>), dim3(n_tiles, (a.Nout + 127) / 128), dim3(256), 0, st, a);
+        const int ny = (a.Nout + 127) / 128;
+        // problems that do not even give every CU one 128-row workgroup take 64-row workgroups: the launch is one
+        // round either way, and its duration is one workgroup's latency
+        if (n_tiles * ny <= 256) hipLaunchKernelGGL((k_rowgemm<1, 2, 1, EPI>), dim3(2 * n_tiles, ny), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_rowgemm<1, 4, 1, EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
     }
     BMP_LAUNCH_CHECK();
     return 0;
