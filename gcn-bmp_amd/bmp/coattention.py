@@ -40,7 +40,15 @@ def _size_classes(nr1: np.ndarray, nr2: np.ndarray, device):
     counts = np.bincount(cls, minlength=4)
     if len(counts) > 4:
         raise ValueError("a molecule has more than 128 rows")
-    return torch.from_numpy(order).to(device), [int(c) for c in counts]
+    # Forward: ONE launch sized by the largest class present, biggest pairs first.  Its LDS need is small (48 KB at 96
+    # rows: three workgroups per CU), and three launches of 35..550 workgroups each cost one workgroup's latency apiece.
+    # (The backward keeps the per-class launches: at 108 KB per 96-row pair one launch would run one pair per CU.)
+    top = int(np.nonzero(counts)[0].max())
+    counts_f = [0, 0, 0, 0]
+    counts_f[top] = int(len(cls))
+    order_f = np.argsort(-cls, kind="stable").astype(np.int32)
+    return (torch.from_numpy(order).to(device), [int(c) for c in counts],
+            torch.from_numpy(order_f).to(device), counts_f)
 
 
 def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
@@ -65,7 +73,8 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
                 r1=pb1.mol_row0[:B].contiguous(), n1=pb1.mol_nrows[:B].contiguous(),
                 r2=(pb1.mol_row0[B:] - T1 * R).contiguous(), n2=pb1.mol_nrows[B:].contiguous(),
                 coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
-            pb1._cache[key]["order"], pb1._cache[key]["counts"] = _size_classes(nr[:B], nr[B:], pb1.device)
+            (pb1._cache[key]["order"], pb1._cache[key]["counts"], pb1._cache[key]["order_f"],
+             pb1._cache[key]["counts_f"]) = _size_classes(nr[:B], nr[B:], pb1.device)
         m = pb1._cache[key]
         N1 = m["T1"] * R
         X1, X2 = at1.rows[:N1], at1.rows[N1:]
@@ -79,7 +88,7 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
     coff = np.concatenate(([0], np.cumsum(nr1 * nr2)))
     m = dict(B=pb1.n_mols, T1=pb1.n_tiles, T2=pb2.n_tiles, r1=pb1.mol_row0, n1=pb1.mol_nrows, r2=pb2.mol_row0,
              n2=pb2.mol_nrows, coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
-    m["order"], m["counts"] = _size_classes(nr1, nr2, pb1.device)
+    m["order"], m["counts"], m["order_f"], m["counts_f"] = _size_classes(nr1, nr2, pb1.device)
     return at1.rows, at2.rows, pb1.row_w, pb2.row_w, m, False
 
 
@@ -102,8 +111,8 @@ class NieCoattnFn(Function):
         H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)      # written / read only at rows that belong to a pair
         out1, out2 = f(B, o), f(B, o)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
-                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order"]),
-                                   *meta["counts"], ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
+                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order_f"]),
+                                   *meta["counts_f"], ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
                                    ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(out1),
                                    ptr(out2), stream()), "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
@@ -160,8 +169,8 @@ class PNieFn(Function):
         H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)
         out1, out2 = f(B, o), f(B, o)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
-                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order"]),
-                                   *meta["counts"], ptr(W["WbT"]), ptr(W["ZW1T"]), ptr(W["ZW2T"]), ptr(W["zb"]), ptr(W["wa1"]),
+                                   ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order_f"]),
+                                   *meta["counts_f"], ptr(W["WbT"]), ptr(W["ZW1T"]), ptr(W["ZW2T"]), ptr(W["zb"]), ptr(W["wa1"]),
                                    ptr(W["wa2"]), ptr(W["cbias"]), ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2),
                                    ptr(al1), ptr(al2), ptr(out1), ptr(out2), stream()), "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
