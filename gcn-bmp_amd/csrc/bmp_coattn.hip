@@ -656,6 +656,13 @@ extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d
     if (s3 > slab) slab = s3;
     size_t s4 = bmp_colsum_ws_floats(B, 2 * H + 1);
     if (s4 > slab) slab = s4;
+    {
+        const WGArgs g[3] = {WGArgs{nullptr, nullptr, d, 0, nullptr, d, d, d, N2, nullptr, d, 0, nullptr, 0, nullptr},
+                             WGArgs{nullptr, nullptr, d, 0, nullptr, ZC, d, ZC, N1, nullptr, ZC, 0, (float*)16, 0, nullptr},
+                             WGArgs{nullptr, nullptr, d, 0, nullptr, ZC, d, ZC, N2, nullptr, ZC, 0, (float*)16, 1, nullptr}};
+        const size_t s5 = bmp_wgrad_multi_ws_floats(g, 3);
+        if (s5 > slab) slab = s5;
+    }
     // dQ2 [N2 x d] | dZ1 [N1 x ZC] | dZ2 [N2 x ZC] | dpart [B x (2H+1)] | slab
     return (size_t)N2 * d + (size_t)(N1 + N2) * ZC + (size_t)B * (2 * H + 1) + slab;
 }
@@ -725,14 +732,17 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
         g.nsrc = 2; g.Nout = d; g.Y = dX2; g.ldy = d;
         if ((rc = bmp_launch_rowgemm(g, n_tiles2, BMP_EPI_GENERIC, st))) return rc;
     }
-    {
-        WGArgs g{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0};
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
-        // dzb = column sums of dZ1 and dZ2: they ride along with the two GEMMs that read those arrays anyway
-        WGArgs g1{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0, dzb, 0};
-        if ((rc = bmp_launch_wgrad(g1, slab, st))) return rc;
-        WGArgs g2{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb, 1};
-        if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
+    {   // the three weight gradients: a few tiles each, one launch.  dzb = column sums of dZ1 and dZ2: they ride along
+        // with the two GEMMs that read those arrays anyway (the second reduction accumulates into the first's result)
+        const WGArgs g[3] = {WGArgs{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0, nullptr, 0, nullptr},
+                             WGArgs{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0, dzb, 0, nullptr},
+                             WGArgs{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb, 1, nullptr}};
+        if (d <= 128 && d >= 64 && ZC >= 64) {
+            if ((rc = bmp_launch_wgrad_multi(g, 3, slab, st))) return rc;
+        } else {
+            for (int p = 0; p < 3; ++p)
+                if ((rc = bmp_launch_wgrad(g[p], slab, st))) return rc;
+        }
     }
     return bmp_launch_colsum(dpart, 2 * H + 1, B, 2 * H + 1, dwa, 0, slab, st);
 }

@@ -1,5 +1,6 @@
 // fp32-MFMA GEMM building blocks for gfx950: the row GEMM (atom-row tiles x weights) and the
 // weight-gradient GEMM (reduction over atom rows).  See bmp_kernels.h for the contracts.
+#include <string.h>
 #include "bmp_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -323,22 +324,21 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ 
 // emits the column sums of dY (bias gradients) as slab row K: dY is being read anyway.
 // ---------------------------------------------------------------------------------------------
 #define WG_LD 132
+typedef float WgStage[32][WG_LD];
 template <bool HAS_X2>
-__global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
-    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
-    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
+__device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, int bx, int by, int bz, WgStage* XS, WgStage* YS) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int i_tile = blockIdx.x * 128, j_tile = blockIdx.y * 128;
-    const int s = blockIdx.z;
+    const int i_tile = bx * 128, j_tile = by * 128;
+    const int s = bz;
     const int r_begin = s * a.rows_per_split;
     const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
     const int nst = (r_end - r_begin) >> 5;
     const int c4 = tid & 31, rr = tid >> 5;
     const int colx = i_tile + 4 * c4, coly = j_tile + 4 * c4;
     const bool okx = colx < a.K, oky = coly < a.Nn;
-    const bool do_cs = want_cs && blockIdx.x == 0;
+    const bool do_cs = want_cs && bx == 0;
     const int Krows = a.K + (want_cs ? 1 : 0);
 
     f32x16 acc[2][2];
@@ -435,6 +435,27 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
     }
 }
 
+template <bool HAS_X2>
+__global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
+    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
+    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
+    wgrad_lds_body<HAS_X2>(a, want_cs, blockIdx.x, blockIdx.y, blockIdx.z, XS, YS);
+}
+
+// Up to three independent problems in one launch (column tiles [ty0[p], ty0[p+1]) belong to problem p; each has its
+// own row count, split size and slab).  For problems that are a launch of 1-2 tiles x ~128 splits each: back to back
+// every one of them lasts one workgroup's latency, side by side they share it.  ONE staging area: an LDS array per
+// instantiated body would halve the workgroups per CU.
+struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; };
+__global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
+    __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
+    __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
+    const int by = blockIdx.y;
+    const int p = by >= m.ty0[2] ? 2 : (by >= m.ty0[1] ? 1 : 0);
+    if ((int)blockIdx.z >= m.S[p]) return;
+    wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], blockIdx.z, XS, YS);
+}
+
 static void wgrad_plan(int N, int K, int Nn, int& mb, int& nb, int& S, int& rps) {
     mb = K > 32 ? 2 : 1;
     nb = Nn > 32 ? 2 : 1;
@@ -524,6 +545,67 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
                        (float*)nullptr, 0);
     BMP_LAUNCH_CHECK();
     if (a.cs) return bmp_launch_colsum(a.dY, a.ldy, a.N, a.Nn, a.cs, a.accumulate | a.cs_accumulate, ws, st);
+    return 0;
+}
+
+// n <= 3 problems with K <= 128 and no X2, one GEMM launch + one reduction each.  ws: bmp_wgrad_multi_ws_floats.
+static void wgrad_multi_plan(const WGArgs* a, int n, int* S, int* rps, int* ty0) {
+    int tiles = 0;
+    for (int p = 0; p < n; ++p) { ty0[p] = tiles; tiles += (a[p].Nn + 127) / 128; }
+    for (int p = n; p <= 3; ++p) ty0[p] = tiles;
+    for (int p = 0; p < n; ++p) {
+        int s = 512 / tiles;
+        int max_s = a[p].N / 256;
+        if (max_s < 1) max_s = 1;
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+        int r = (a[p].N + s - 1) / s;
+        r = (r + 31) & ~31;
+        rps[p] = r; S[p] = (a[p].N + r - 1) / r;
+    }
+}
+
+size_t bmp_wgrad_multi_ws_floats(const WGArgs* a, int n) {
+    int S[3], rps[3], ty0[4];
+    wgrad_multi_plan(a, n, S, rps, ty0);
+    size_t tot = 0;
+    for (int p = 0; p < n; ++p) tot += (size_t)S[p] * (a[p].K + 1) * a[p].Nn;
+    return tot;
+}
+
+int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
+    BMP_REQUIRE(n >= 1 && n <= 3 && ws != nullptr);
+    WGKMulti m; memset(&m, 0, sizeof(m));
+    int rps[3];
+    for (int p = 0; p < n; ++p) BMP_REQUIRE(a[p].K <= 128 && !a[p].X2 && !a[p].onehot && wgrad_use_lds(a[p]));
+    wgrad_multi_plan(a, n, m.S, rps, m.ty0);
+    float* slab[3];
+    size_t off = 0;
+    int smax = 0;
+    double flops = 0, bytes = 0;
+    for (int p = 0; p < n; ++p) {
+        slab[p] = ws + off;
+        m.want_cs[p] = a[p].cs != nullptr;
+        m.p[p] = WGKArgs{a[p].X, nullptr, a[p].ldx, 0, a[p].dY, a[p].ldy, a[p].K, a[p].Nn, a[p].N, rps[p], slab[p], nullptr};
+        off += (size_t)m.S[p] * (a[p].K + m.want_cs[p]) * a[p].Nn;
+        if (m.S[p] > smax) smax = m.S[p];
+        flops += 2.0 * a[p].N * (double)a[p].K * a[p].Nn;
+        bytes += 4.0 * a[p].N * ((double)a[p].K + a[p].Nn);
+    }
+    {
+        BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st);
+        hipLaunchKernelGGL(k_wgrad_lds_multi, dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
+    }
+    BMP_LAUNCH_CHECK();
+    for (int p = 0; p < n; ++p) {
+        const int Krows = a[p].K + m.want_cs[p];
+        const size_t total = (size_t)Krows * a[p].Nn;
+        int blocks = (int)((total + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, slab[p], m.S[p], Krows, a[p].Nn, a[p].out, a[p].ldo,
+                           a[p].accumulate, m.want_cs[p] ? a[p].K : -1, a[p].cs, a[p].accumulate | a[p].cs_accumulate);
+        BMP_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -63,6 +63,9 @@ struct WGArgs {
 };
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
+// n <= 3 independent problems (K <= 128, no X2) in ONE GEMM launch: for launches of a few tiles each
+size_t bmp_wgrad_multi_ws_floats(const WGArgs* a, int n);
+int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st);
 
 // column sums: out[n] (=|+=) sum_rows dY[row, n]
 size_t bmp_colsum_ws_floats(int N, int Nn);
