@@ -608,17 +608,16 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && n32 + n64 + n96 + n128 == B);
     const int ZC = bmp_coattn_zcols(o, H);
     int rc;
-    {
-        RGArgs g; memset(&g, 0, sizeof(g));
-        g.s[0] = RGSrc{X2, nullptr, WbT, d, 0, d, d};
-        g.nsrc = 1; g.Nout = d; g.Y = Q2; g.ldy = d;
-        if ((rc = bmp_launch_rowgemm(g, n_tiles2, BMP_EPI_GENERIC, st))) return rc;
-    }
-    for (int s = 0; s < 2; ++s) {
-        RGArgs g; memset(&g, 0, sizeof(g));
-        g.s[0] = RGSrc{s == 0 ? X1 : X2, nullptr, s == 0 ? ZW1T : ZW2T, d, 0, ZC, d};
-        g.nsrc = 1; g.Nout = ZC; g.Y = s == 0 ? Z1 : Z2; g.ldy = ZC; g.bias = zb;
-        if ((rc = bmp_launch_rowgemm(g, s == 0 ? n_tiles1 : n_tiles2, BMP_EPI_GENERIC, st))) return rc;
+    {   // Q2 = X2 . WbT ; Z1 = X1 . ZW1T + zb ; Z2 = X2 . ZW2T + zb : three projections, one launch
+        RGArgs g[3]; memset(g, 0, sizeof(g));
+        g[0].s[0] = RGSrc{X2, nullptr, WbT, d, 0, d, d};
+        g[0].nsrc = 1; g[0].Nout = d; g[0].Y = Q2; g[0].ldy = d;
+        for (int s = 0; s < 2; ++s) {
+            g[1 + s].s[0] = RGSrc{s == 0 ? X1 : X2, nullptr, s == 0 ? ZW1T : ZW2T, d, 0, ZC, d};
+            g[1 + s].nsrc = 1; g[1 + s].Nout = ZC; g[1 + s].Y = s == 0 ? Z1 : Z2; g[1 + s].ldy = ZC; g[1 + s].bias = zb;
+        }
+        const int nt[3] = {n_tiles2, n_tiles1, n_tiles2};
+        if ((rc = bmp_launch_rowgemm_multi(g, nt, 3, st))) return rc;
     }
     const void* kf = H == 8 ? (const void*)k_coattn_fwd<8> : H == 4 ? (const void*)k_coattn_fwd<4> : (const void*)k_coattn_fwd<0>;
     if ((rc = co_set_lds(kf, 160 * 1024))) return rc;
@@ -719,18 +718,15 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
             off += cnt[c];
         }
     }
-    {   // dX1 += dZ1 . ZW1   (K = ZC)
-        RGArgs g; memset(&g, 0, sizeof(g));
-        g.s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};
-        g.nsrc = 1; g.Nout = d; g.Y = dX1; g.ldy = d; g.accumulate = 1;
-        if ((rc = bmp_launch_rowgemm(g, n_tiles1, BMP_EPI_GENERIC, st))) return rc;
-    }
-    {   // dX2 = dQ2 . W + dZ2 . ZW2
-        RGArgs g; memset(&g, 0, sizeof(g));
-        g.s[0] = RGSrc{dQ2, nullptr, Wb, d, 0, d, d};
-        g.s[1] = RGSrc{dZ2, nullptr, ZW2, ZC, 0, d, ZC};
-        g.nsrc = 2; g.Nout = d; g.Y = dX2; g.ldy = d;
-        if ((rc = bmp_launch_rowgemm(g, n_tiles2, BMP_EPI_GENERIC, st))) return rc;
+    {   // dX1 += dZ1 . ZW1 (K = ZC) ; dX2 = dQ2 . W + dZ2 . ZW2 : one launch
+        RGArgs g[2]; memset(g, 0, sizeof(g));
+        g[0].s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};
+        g[0].nsrc = 1; g[0].Nout = d; g[0].Y = dX1; g[0].ldy = d; g[0].accumulate = 1;
+        g[1].s[0] = RGSrc{dQ2, nullptr, Wb, d, 0, d, d};
+        g[1].s[1] = RGSrc{dZ2, nullptr, ZW2, ZC, 0, d, ZC};
+        g[1].nsrc = 2; g[1].Nout = d; g[1].Y = dX2; g[1].ldy = d;
+        const int nt[2] = {n_tiles1, n_tiles2};
+        if ((rc = bmp_launch_rowgemm_multi(g, nt, 2, st))) return rc;
     }
     {   // the three weight gradients: a few tiles each, one launch.  dzb = column sums of dZ1 and dZ2: they ride along
         // with the two GEMMs that read those arrays anyway (the second reduction accumulates into the first's result)

@@ -46,20 +46,19 @@ __device__ __forceinline__ void rg_epilogue(const RGArgs& a, int row, int col, f
 // RB x CBW blocks of 32x32.  R = WR*RB*32 = 128 rows, NT = WC*CBW*32 columns per workgroup.
 // ---------------------------------------------------------------------------------------------
 template <int WR, int RB, int CBW, int EPI>
-__global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
+__device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, float* lds) {
     constexpr int WC = 4 / WR;
     constexpr int NT = WC * CBW * 32;
     constexpr int R = WR * RB * 32;                     // rows per workgroup: 128, or 64 for the small problems
     static_assert(R == BMP_R || R == BMP_R / 2, "a workgroup takes a whole or half a 128-row tile");
-    __shared__ __attribute__((aligned(16))) float lds[R * BMP_LDS_LD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int wr = w / WC, wc = w % WC;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * R;
-    const int n0 = blockIdx.y * NT;
+    const int row0 = bx * R;
+    const int n0 = by * NT;
 
     f32x16 acc[RB][CBW];
 #pragma unroll
@@ -178,6 +177,23 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
         }
 }
 
+template <int WR, int RB, int CBW, int EPI>
+__global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[WR * RB * 32 * BMP_LDS_LD];
+    rowgemm_body<WR, RB, CBW, EPI>(a, blockIdx.x, blockIdx.y, lds);
+}
+
+// Up to three independent row GEMMs (generic epilogue) in one launch: row tiles [tx0[p], tx0[p+1]) belong to problem
+// p.  The co-attention's projections are 228 tiles each -- alone, every one of them lasts one workgroup's latency.
+struct RGMulti { RGArgs p[3]; int tx0[4]; int ny[3]; };
+__global__ __launch_bounds__(256) void k_rowgemm_multi(RGMulti m) {
+    __shared__ __attribute__((aligned(16))) float lds[(BMP_R / 2) * BMP_LDS_LD];
+    const int bx = blockIdx.x;                         // 64-row workgroups: two per 128-row tile
+    const int p = bx >= 2 * m.tx0[2] ? 2 : (bx >= 2 * m.tx0[1] ? 1 : 0);
+    if ((int)blockIdx.y >= m.ny[p]) return;
+    rowgemm_body<1, 2, 1, BMP_EPI_GENERIC>(m.p[p], bx - 2 * m.tx0[p], blockIdx.y, lds);
+}
+
 template <int EPI>
 static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
     if (a.Nout <= 32) {
@@ -212,6 +228,33 @@ int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st) {
         case BMP_EPI_GRU_DRH: return launch_rowgemm_epi<BMP_EPI_GRU_DRH>(a, n_tiles, st);
     }
     return -1;
+}
+
+int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStream_t st) {
+    BMP_REQUIRE(n >= 1 && n <= 3);
+    RGMulti m; memset(&m, 0, sizeof(m));
+    int tiles = 0, nymax = 0;
+    double flops = 0, bytes = 0;
+    for (int p = 0; p < n; ++p) {
+        BMP_REQUIRE(n_tiles[p] > 0 && a[p].Nout > 0 && a[p].nsrc >= 1 && a[p].nsrc <= 3);
+        double ksum = 0;
+        for (int s = 0; s < a[p].nsrc; ++s) {
+            BMP_REQUIRE(a[p].s[s].K > 0 && (a[p].s[s].K & 7) == 0 && (a[p].s[s].ldx & 3) == 0 && ((uintptr_t)a[p].s[s].X & 15) == 0);
+            if (a[p].s[s].X2) BMP_REQUIRE((a[p].s[s].ldx2 & 3) == 0 && ((uintptr_t)a[p].s[s].X2 & 15) == 0);
+            ksum += a[p].s[s].K;
+        }
+        m.p[p] = a[p];
+        m.tx0[p] = tiles; tiles += n_tiles[p];
+        m.ny[p] = (a[p].Nout + 127) / 128;
+        if (m.ny[p] > nymax) nymax = m.ny[p];
+        const double rows = (double)n_tiles[p] * BMP_R;
+        flops += 2.0 * rows * ksum * a[p].Nout; bytes += 4.0 * rows * (ksum + a[p].Nout);
+    }
+    for (int p = n; p <= 3; ++p) m.tx0[p] = tiles;
+    BmpProfScope prof(BMP_KCLS_ROWGEMM, flops, bytes, st);
+    hipLaunchKernelGGL(k_rowgemm_multi, dim3(2 * tiles, nymax), dim3(256), 0, st, m);
+    BMP_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -46,6 +46,8 @@ struct RGArgs {
 };
 
 int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st);
+// n <= 3 independent problems (generic epilogue) in ONE launch
+int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // Weight-gradient GEMM:  out[K x Nn] (=|+=) sum_rows X[row, k] (* X2) . dY[row, n]
