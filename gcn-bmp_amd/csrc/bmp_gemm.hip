@@ -6,14 +6,25 @@
 // ---------------------------------------------------------------------------------------------
 // epilogues
 // ---------------------------------------------------------------------------------------------
+// Per-column constants of the epilogue, loaded ONCE per lane and column block: inside the element loop the stores to Y
+// may alias them as far as the compiler knows, so it reloaded bias[col] (and waited for it) after every store.
+struct RGCol { float bias; float bE[4]; };
+__device__ __forceinline__ RGCol rg_col(const RGArgs& a, int col) {
+    RGCol c;
+    c.bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c.bE[e] = a.wdeg ? a.bE[(size_t)e * a.ldbE + col] : 0.f;
+    return c;
+}
+
 template <int EPI>
-__device__ __forceinline__ void rg_epilogue(const RGArgs& a, int row, int col, float v) {
-    if (a.bias) v += a.bias[col];
+__device__ __forceinline__ void rg_epilogue(const RGArgs& a, const RGCol& cc, int row, int col, float v) {
+    v += cc.bias;
     if (EPI == BMP_EPI_GENERIC) {
         if (a.wdeg) {
-            const float* wd = a.wdeg + (size_t)row * 4;
+            const f32x4 wd = *(const f32x4*)(a.wdeg + (size_t)row * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v += wd[e] * a.bE[(size_t)e * a.ldbE + col];
+            for (int e = 0; e < 4; ++e) v += wd[e] * cc.bE[e];
         }
         const bool lo = (a.split <= 0) || (col < a.split);
         if (a.add && lo) v += a.add[(size_t)row * a.ldadd + col];
@@ -168,10 +179,11 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
         for (int cb = 0; cb < CBW; ++cb) {
             const int col = n0 + (wc * CBW + cb) * 32 + l31;
             if (col < a.Nout) {
+                const RGCol cc = rg_col(a, col);
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int row = row0 + (wr * RB + rb) * 32 + bmp_acc_row(reg, lane);
-                    rg_epilogue<EPI>(a, row, col, acc[rb][cb][reg]);
+                    rg_epilogue<EPI>(a, cc, row, col, acc[rb][cb][reg]);
                 }
             }
         }
