@@ -357,15 +357,23 @@ class LinearRowsFn(Function):
 # autograd only carries the row tensors.  ``tape`` is a dummy 1-element tensor that requires grad: it makes
 # autograd run the backward of ops whose only differentiable input would have been a weight.
 # ---------------------------------------------------------------------------------------------------------
+def _first_write(state, key) -> bool:
+    """True the first time a gradient buffer of the plan is written in this backward (the kernel overwrites it);
+    later writers (the encoder is called once per side in the reference's four-array form) go through a temporary."""
+    first = not state.get(key)
+    state[key] = True
+    return first
+
+
 class PEmbedFn(Function):
     @staticmethod
-    def forward(ctx, tape, W, ids, dW):
+    def forward(ctx, tape, W, ids, dW, state):
         L = _lib.lib()
         V, d = W.shape
         N = ids.numel()
         out = torch.empty(N, d, dtype=torch.float32, device=W.device)
         check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, ptr(out), stream()), "bmp_embed_fwd")
-        ctx.ids, ctx.dW, ctx.V = ids, dW, V
+        ctx.ids, ctx.dW, ctx.V, ctx.state = ids, dW, V, state
         return out
 
     @staticmethod
@@ -375,8 +383,12 @@ class PEmbedFn(Function):
         N, d = dout.shape
         nws = L.bmp_embed_bwd_ws_floats(N, d, ctx.V)
         ws = _ws(nws, dout.device)
-        check(L.bmp_embed_bwd(ptr(ctx.ids), ptr(dout), N, d, ctx.V, ptr(ctx.dW), ptr(ws), nws, stream()), "bmp_embed_bwd")
-        return None, None, None, None
+        first = _first_write(ctx.state, "embed.dW")
+        dst = ctx.dW if first else torch.empty_like(ctx.dW)
+        check(L.bmp_embed_bwd(ptr(ctx.ids), ptr(dout), N, d, ctx.V, ptr(dst), ptr(ws), nws, stream()), "bmp_embed_bwd")
+        if not first:
+            ctx.dW.add_(dst)
+        return None, None, None, None, None
 
 
 class PStepFn(Function):
@@ -423,12 +435,13 @@ class PReadoutFn(Function):
     """ReadoutFn on prepared weights.  W: WT, b, Wnat; G: dWT, db."""
 
     @staticmethod
-    def forward(ctx, h, h0, pb, W, G, act_j):
+    def forward(ctx, h, h0, pb, W, G, act_j, state):
         L = _lib.lib()
         require_rows(h, "readout: h")
         _check_pb(pb, h)
         N, d = h.shape
         d0 = h0.shape[1]
+        ctx.state = state
         WT = W["WT"]
         o = WT.shape[1] // 2
         ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
@@ -451,7 +464,12 @@ class PReadoutFn(Function):
         dh, dh0 = torch.empty_like(h), torch.empty_like(h0)
         nws = L.bmp_readout_bwd_ws_floats(pb.n_tiles, d, d0, o)
         ws = _ws(nws, h.device)
+        first = _first_write(ctx.state, "ro")
+        dWT = G["dWT"] if first else torch.empty_like(G["dWT"])
+        db = G["db"] if first else torch.empty_like(G["db"])
         check(L.bmp_readout_bwd(ptr(dg), ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(W["Wnat"]), ptr(ij), ctx.act_j,
                                 ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0),
-                                ptr(G["dWT"]), ptr(G["db"]), ptr(ws), nws, stream()), "bmp_readout_bwd")
-        return dh, dh0, None, None, None, None
+                                ptr(dWT), ptr(db), ptr(ws), nws, stream()), "bmp_readout_bwd")
+        if not first:
+            G["dWT"].add_(dWT); G["db"].add_(db)
+        return dh, dh0, None, None, None, None, None

@@ -215,7 +215,7 @@ class GGNN(nn.Module):
         """The encoder on the plan's prepared weights: embed, fused steps, readout -- no layout work, no weight
         gradients through autograd."""
         P, G, state, tape = fast
-        h = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"])
+        h = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
         h0 = h
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
@@ -225,7 +225,7 @@ class GGNN(nn.Module):
             h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0)
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
-                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"])
+                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state)
 
     def forward(self, atom_array, adj=None):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``

@@ -175,6 +175,7 @@ class LayoutPlan:
         else:       # host form of the same table walk (tests of the tables without a GPU)
             self.prep.copy_(gather_sum_host(flat.detach(), self.tab_p_host))
         self.state = {}
+        self.gk.zero_()          # a buffer no backward kernel writes this step (an unused readout, ...) must read as zero
 
     def collect(self, flat_grad: torch.Tensor) -> None:
         """One launch: flat_grad[j] += the parameter gradients folded out of the kernels' buffers."""

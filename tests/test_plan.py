@@ -101,3 +101,30 @@ def test_planned_step_equals_eager_step(attn):
     a_t = 1e-3 * (1 - 0.999) ** 0.5 / (1 - 0.9)
     want = p0 - a_t * m / (v.sqrt() + 1e-8)
     assert torch.allclose(opt.flat, want, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_planned_step_with_the_reference_four_array_call():
+    """The reference's call form runs the encoder once per side: the plan's gradient buffers must accumulate over both
+    calls (embedding, readout, step groups), and nothing stale may survive from the step before."""
+    from bmp import synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(30, seed=8, n_lo=4, n_hi=30, n_mean=10)
+    a1, j1 = synth.concat_mols([store[k] for k in range(0, 10)])
+    a2, j2 = synth.concat_mols([store[k] for k in range(10, 20)])
+    t = (torch.arange(10, device=dev) % 2).int().view(-1, 1)
+    torch.manual_seed(2)
+    model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=2, attn="parallel", head=1).to(dev)   # uses g1, g2: readout trains
+    y = model(a1, j1, a2, j2)
+    model.loss(y, t).backward()
+    eager = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()]).clone()
+    opt = FlatAdam(model, alpha=1e-3)
+    for _ in range(2):                                   # twice: the second step must not see the first one's buffers
+        y2 = opt.functional_forward(a1, j1, a2, j2)
+        model.loss(y2, t).backward()
+        opt.collect_grads()
+        scale = eager.abs().max().item()
+        assert (opt.grad - eager).abs().max().item() <= 1e-5 * scale
+    assert opt.plan is not None and "graph_conv." in opt.plan.P
