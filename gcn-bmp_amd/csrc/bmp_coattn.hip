@@ -588,8 +588,17 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static int co_set_lds(const void* fn, size_t bytes) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? 0 : (int)e;
+    static const void* done[8] = {nullptr};        // the six kernel instances: set once each, not per launch
+    for (int i = 0; i < 8; ++i) {
+        if (done[i] == fn) return 0;
+        if (done[i] == nullptr) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) return (int)e;
+            done[i] = fn;
+            return 0;
+        }
+    }
+    return -1;
 }
 
 // ZC = o + H + 1 rounded up to a multiple of 8: J (o) | P (H) | v | pad

@@ -555,8 +555,12 @@ extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 template <int D, bool FIRST>
 static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
     const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST> : (const void*)k_ggnn_step_fwd<D, FIRST>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
-    if (e != hipSuccess) return (int)e;
+    static bool attr_set[2] = {false, false};      // per template instance, per direction: set once, not per launch
+    if (!attr_set[bwd ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
+        if (e != hipSuccess) return (int)e;
+        attr_set[bwd ? 1 : 0] = true;
+    }
     const double rows = (double)n_tiles * FZ_R;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,

@@ -33,8 +33,9 @@ extern "C" int bmp_gather_sum(float* dst, int n, const float* src, const int* id
 // chainer Adam: m += (1-b1)(g-m); v += (1-b2)(g^2-v); p -= alpha_t * m / (sqrt(v) + eps) + wd * p
 // (alpha_t = alpha * sqrt(1-b2^t)/(1-b1^t) is computed by the caller; eps sits outside the bias correction).
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, int n, float alpha_t, float b1, float b2, float eps,
-                                              float wd, float gscale) {
+                                              float* __restrict__ v, int n, float alpha_host, const float* __restrict__ alpha_dev,
+                                              float b1, float b2, float eps, float wd, float gscale) {
+    const float alpha_t = alpha_dev ? alpha_dev[0] : alpha_host;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -46,14 +47,15 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
-extern "C" int bmp_adam_step(float* p, const float* g, float* m, float* v, int n, float alpha_t, float beta1, float beta2,
-                             float eps, float weight_decay_rate, float grad_scale, hipStream_t st) {
+// alpha_t_dev (optional, device): read instead of alpha_t -- the step-dependent factor of a launch recorded in a HIP graph.
+extern "C" int bmp_adam_step(float* p, const float* g, float* m, float* v, int n, float alpha_t, const float* alpha_t_dev,
+                             float beta1, float beta2, float eps, float weight_decay_rate, float grad_scale, hipStream_t st) {
     BMP_REQUIRE(n >= 0 && p && g && m && v);
     if (n == 0) return 0;
     int blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, alpha_t, beta1, beta2, eps, weight_decay_rate,
-                       grad_scale);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, alpha_t, alpha_t_dev, beta1, beta2, eps,
+                       weight_decay_rate, grad_scale);
     BMP_LAUNCH_CHECK();
     return 0;
 }

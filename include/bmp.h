@@ -196,10 +196,11 @@ int bmp_pairfeat_bwd(int kind, const float* dout, const float* x1, const float* 
  * bmp_gather_sum: dst[i] (=|+=) sum_k src[idx[k*n + i]] over table entries >= 0 (idx is [K][n] int32).  One launch
  * builds every kernel-layout weight array from the flat parameter buffer; one more folds the weight-gradient
  * buffers back into the flat gradient (bmp/plan.py builds the tables).
- * bmp_adam_step: m += (1-b1)(g-m); v += (1-b2)(g^2-v); p = p(1-wd) - alpha_t m/(sqrt(v)+eps), g scaled by grad_scale. */
+ * bmp_adam_step: m += (1-b1)(g-m); v += (1-b2)(g^2-v); p = p(1-wd) - alpha_t m/(sqrt(v)+eps), g scaled by grad_scale;
+ * alpha_t_dev (device, may be NULL) overrides alpha_t: the step-dependent factor of a launch recorded in a HIP graph. */
 int bmp_gather_sum(float* dst, int n, const float* src, const int* idx, int K, int accumulate, bmp_stream_t stream);
-int bmp_adam_step(float* p, const float* g, float* m, float* v, int n, float alpha_t, float beta1, float beta2, float eps,
-                  float weight_decay_rate, float grad_scale, bmp_stream_t stream);
+int bmp_adam_step(float* p, const float* g, float* m, float* v, int n, float alpha_t, const float* alpha_t_dev, float beta1,
+                  float beta2, float eps, float weight_decay_rate, float grad_scale, bmp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -128,3 +128,44 @@ def test_planned_step_with_the_reference_four_array_call():
         scale = eager.abs().max().item()
         assert (opt.grad - eager).abs().max().item() <= 1e-5 * scale
     assert opt.plan is not None and "graph_conv." in opt.plan.P
+
+
+@pytest.mark.gpu
+def test_graphed_training_steps_equal_eager_steps():
+    """bmp.dp.GraphedTrainStep: a step recorded as a HIP graph and replayed leaves the same parameters as the eager
+    step (same kernels, same order), over several steps and two alternating batches."""
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam, GraphedTrainStep
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(40, seed=3, n_lo=4, n_hi=40, n_mean=14)
+    ms = packed.MolStore(store)
+    batches = []
+    for k in range(2):
+        i1, i2 = np.arange(16 * k, 16 * k + 8), np.arange(16 * k + 8, 16 * k + 16)
+        batches.append((packed.pack_from_store(ms, [i1, i2], device=dev), (torch.arange(8, device=dev) % 2).int().view(-1, 1)))
+
+    def run(graphed):
+        torch.manual_seed(4)
+        model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=2, attn="nie", head=4).to(dev)
+        opt = FlatAdam(model, alpha=1e-2)
+        stepper = GraphedTrainStep(model, opt) if graphed else None
+        losses = []
+        for s in range(6):
+            pb, t = batches[s % 2]
+            if graphed:
+                losses.append(float(stepper(pb, t).detach()))
+            else:
+                y = opt.functional_forward(pb)
+                loss = model.loss(y, t)
+                loss.backward()
+                opt.collect_grads(); opt.all_reduce_grads(); opt.step()
+                losses.append(float(loss.detach()))
+        return opt.flat.clone(), losses, opt.t
+
+    p_eager, l_eager, t_eager = run(False)
+    p_graph, l_graph, t_graph = run(True)
+    assert t_eager == t_graph == 6
+    assert np.allclose(l_eager, l_graph, rtol=1e-5, atol=1e-6), (l_eager, l_graph)
+    assert (p_eager - p_graph).abs().max().item() <= 1e-5 * p_eager.abs().max().item()
+    assert l_eager[-1] < l_eager[0]

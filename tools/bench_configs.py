@@ -17,14 +17,17 @@ import torch            # noqa: E402
 
 from bmp import synth, packed                         # noqa: E402
 from bmp.predictor import build_pair_predictor        # noqa: E402
-from bmp.dp import FlatAdam                           # noqa: E402
+from bmp.dp import FlatAdam, GraphedTrainStep         # noqa: E402
 
 
-def run(name, model, batches, B, steps=20, warmup=5):
+def run(name, model, batches, B, steps=20, warmup=5, graphed=False):
     opt = FlatAdam(model, alpha=1e-3)
+    stepper = GraphedTrainStep(model, opt) if graphed else None
 
     def step(i):
         pb, t = batches[i % len(batches)]
+        if graphed:                         # one HIP-graph replay per step (recorded at the batch's first use)
+            return stepper(pb, t)
         y = opt.functional_forward(pb)
         loss = model.loss(y, t)
         loss.backward()
@@ -70,6 +73,9 @@ def main():
                             torch.from_numpy(lab[sl].reshape(-1, 1)).to(dev)))
         model = build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, attn="nie").to(dev)
         run("C2 model at the reference's batch of 32 pairs", model, batches, B, steps=50)
+        torch.manual_seed(777)
+        model = build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, attn="nie").to(dev)
+        run("C2 model at batch 32, steps replayed as HIP graphs", model, batches, B, steps=200, warmup=len(batches), graphed=True)
     if "C4" in which:
         store = synth.make_store(1704, seed=2018)
         ms = packed.MolStore(store)
