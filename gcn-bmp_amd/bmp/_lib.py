@@ -50,6 +50,8 @@ SIGNATURES = {
     "bmp_rowbcast_bwd": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "bmp_rowdot_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "bmp_rowdot_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bmp_dense_count": (_I, [_P, _I, _I, _P, _P, _P]),
+    "bmp_dense_to_csr": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P]),
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),
     "bmp_mlp_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -95,6 +95,12 @@ def as_packed(atom_array, adj, device) -> PackedMolBatch:
     numpy or torch) or an already packed batch in the first slot."""
     if isinstance(atom_array, PackedMolBatch):
         return atom_array
+    if isinstance(adj, torch.Tensor) and adj.is_cuda:        # dense device arrays: the adjacency never crosses PCIe
+        a = atom_array.detach().cpu().numpy() if isinstance(atom_array, torch.Tensor) else np.asarray(atom_array)
+        if a.dtype.kind not in "iu":
+            raise NotImplementedError("float atom features (embedding bypass, models/ggnn.py:604-605) are not supported")
+        from .packed import pack_from_dense_device
+        return pack_from_dense_device([a.astype(np.int32)], [adj.detach().float().contiguous()])
     a = atom_array.detach().cpu().numpy() if isinstance(atom_array, torch.Tensor) else np.asarray(atom_array)
     j = adj.detach().cpu().numpy() if isinstance(adj, torch.Tensor) else np.asarray(adj)
     if a.dtype.kind not in "iu":

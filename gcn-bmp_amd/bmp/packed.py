@@ -313,3 +313,95 @@ def unpack_to_dense(pb: PackedMolBatch, side: int = 0) -> Tuple[np.ndarray, np.n
     keep = (pos_b[row_of_edge] >= 0) & (pos_b[src] >= 0)
     adj[pos_b[row_of_edge][keep], (col & 3)[keep], pos_a[row_of_edge][keep], pos_a[src][keep]] = val[keep]
     return atoms, adj
+
+
+def pack_from_dense_device(atom_arrays: Sequence, adjs: Sequence[torch.Tensor], R: int = DEFAULT_R) -> PackedMolBatch:
+    """pack_from_dense for adjacency tensors that already live on the GPU (the reference's call form hands the
+    encoders dense device arrays, train_binary.py:85-89): the dense (mb, 4, A, A) array -- 260 MB for 1024 pairs --
+    never crosses PCIe.  The device counts the bonds per position (bmp_dense_count); the host, which only needs
+    those counts and the atom ids (mb x A integers), places the molecules into tiles exactly as pack_from_dense does;
+    the device then writes the CSR entries in the host packer's order (bmp_dense_to_csr).  Bit-identical to
+    pack_from_dense (tests/test_gpu_dense.py).  Inputs with bonds leaving a padded position (atom id 0, no incoming
+    bond: only possible with an asymmetric adjacency) fall back to the host packer."""
+    from . import _lib
+    from ._lib import check, ptr, stream
+    L = _lib.lib()
+    dev = adjs[0].device
+    atoms_np, counts = [], []
+    for atoms, adj in zip(atom_arrays, adjs):
+        a = atoms.detach().cpu().numpy() if isinstance(atoms, torch.Tensor) else np.asarray(atoms)
+        if adj.dtype != torch.float32 or not adj.is_cuda or not adj.is_contiguous():
+            raise ValueError("adjacency must be a contiguous float32 CUDA tensor")
+        mb, A = a.shape
+        if tuple(adj.shape) != (mb, NUM_EDGE_TYPE, A, A):
+            raise ValueError(f"adj shape {tuple(adj.shape)} does not match atoms {a.shape}")
+        cnt = torch.empty(2, mb, A, dtype=torch.int32, device=dev)
+        check(L.bmp_dense_count(ptr(adj), mb, A, ptr(cnt[0]), ptr(cnt[1]), stream()), "bmp_dense_count")
+        atoms_np.append(a.astype(np.int32)); counts.append(cnt)
+    counts = [c.cpu().numpy().astype(np.int64) for c in counts]              # one small D2H per side
+    inst_nrows_l, flat_atom_l, flat_w_l, side_l, dmf, rown_l, coln_l = [], [], [], [], [], [], []
+    flat_base = 0
+    for k, (atoms, (indeg, outdeg)) in enumerate(zip(atoms_np, counts)):
+        mb, A = atoms.shape
+        padlike = (atoms == 0) & (indeg == 0)
+        if (outdeg[padlike] != 0).any():
+            return pack_from_dense(atoms_np, [a.cpu().numpy() for a in adjs], R=R, device=dev)
+        real = ~padlike
+        n = real.sum(axis=1).astype(np.int64)
+        local = np.cumsum(real, axis=1) - 1
+        nrows = n + 1
+        off = flat_base + np.cumsum(nrows) - nrows
+        dm = np.where(real, off[:, None] + local, (off + n)[:, None])          # (mb, A) flat row
+        fa = np.zeros(int(nrows.sum()), dtype=np.int32)
+        fw = np.ones(int(nrows.sum()), dtype=np.float32)
+        fa[dm[real] - flat_base] = atoms[real]
+        fw[off + n - flat_base] = padlike.sum(axis=1).astype(np.float32)
+        inst_nrows_l.append(nrows); flat_atom_l.append(fa); flat_w_l.append(fw)
+        side_l.append(np.full(mb, k, dtype=np.int64)); dmf.append(dm)
+        rown_l.append(indeg); coln_l.append(outdeg)
+        flat_base += int(nrows.sum())
+    inst_nrows = np.concatenate(inst_nrows_l)
+    side_of = np.concatenate(side_l)
+    I = len(inst_nrows)
+    inst_row0 = np.zeros(I, dtype=np.int64)
+    side_tiles, side_mols, tile0 = [0], [0], 0
+    for s_ in range(len(atoms_np)):
+        sel = np.nonzero(side_of == s_)[0]
+        bins, offs, nb = _bin_pack(inst_nrows[sel], R)
+        inst_row0[sel] = (tile0 + bins) * R + offs
+        tile0 += nb
+        side_tiles.append(tile0); side_mols.append(side_mols[-1] + len(sel))
+    n_tiles = tile0
+    N = n_tiles * R
+    rowmap = _ragged_arange(inst_row0, inst_nrows)                              # flat row -> packed row
+    flat_atom, flat_w = np.concatenate(flat_atom_l), np.concatenate(flat_w_l)
+    atom_id = np.zeros(N, dtype=np.int32); row_w = np.zeros(N, dtype=np.float32)
+    atom_id[rowmap] = flat_atom; row_w[rowmap] = flat_w
+    deg_in = np.zeros(N, dtype=np.int64); deg_out = np.zeros(N, dtype=np.int64)
+    dense_rows = [rowmap[dm] for dm in dmf]                                     # per side: packed row of every dense position
+    for dr, rn, cn in zip(dense_rows, rown_l, coln_l):
+        np.add.at(deg_in, dr.ravel(), rn.ravel()); np.add.at(deg_out, dr.ravel(), cn.ravel())
+    csr_ptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg_in, out=csr_ptr[1:])
+    csrT_ptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg_out, out=csrT_ptr[1:])
+    E = int(csr_ptr[-1])
+    ints = [atom_id, csr_ptr.astype(np.int32), csrT_ptr.astype(np.int32), inst_row0.astype(np.int32),
+            inst_nrows.astype(np.int32)] + [dr.astype(np.int32).ravel() for dr in dense_rows]
+    ibuf = torch.from_numpy(np.concatenate(ints)).to(dev)
+    iv, o = [], 0
+    for a in ints:
+        iv.append(ibuf[o:o + len(a)]); o += len(a)
+    row_w_d = torch.from_numpy(row_w).to(dev)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=dev); val = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    colT = torch.empty_like(col); valT = torch.empty_like(val)
+    for k, adj in enumerate(adjs):
+        mb, A = atoms_np[k].shape
+        check(L.bmp_dense_to_csr(ptr(adj), mb, A, ptr(iv[5 + k]), ptr(iv[1]), 0, ptr(col), ptr(val), stream()), "bmp_dense_to_csr")
+        check(L.bmp_dense_to_csr(ptr(adj), mb, A, ptr(iv[5 + k]), ptr(iv[2]), 1, ptr(colT), ptr(valT), stream()), "bmp_dense_to_csr")
+    dmaps = [torch.from_numpy(dr).to(dev) for dr in dense_rows]
+    return PackedMolBatch(
+        R=R, n_tiles=n_tiles, n_mols=I, atom_id=iv[0], row_w=row_w_d,
+        csr_ptr=iv[1], csr_col=col[:E], csr_val=val[:E], csrT_ptr=iv[2], csrT_col=colT[:E], csrT_val=valT[:E],
+        mol_row0=iv[3], mol_nrows=iv[4], side_tiles=tuple(side_tiles), side_mols=tuple(side_mols),
+        dense_map=dmaps[0] if len(dmaps) == 1 else None, dense_maps=dmaps,
+        n_real_atoms=int((flat_w == 1).sum()), n_edges=E, max_rows_per_mol=int(inst_nrows.max()) if I else 0,
+        mol_nrows_host=inst_nrows.astype(np.int64))

@@ -165,6 +165,14 @@ int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, 
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
                        bmp_stream_t stream);
 
+/* ---- the reference's dense batch on the device (concat_mols, train_ddi_modify.py:296) ----
+ * adj (mb, 4, A, A) float32, zero padded.  bmp_dense_count: bonds per dense position, by row (incoming) and by column
+ * (outgoing).  bmp_dense_to_csr: the entries of the packed CSR of bmp/packed.py (transposed = 1: of its transpose), in
+ * the host packer's order; rowmap [mb x A] = packed row of every dense position, ptr [N + 1] = row pointers. */
+int bmp_dense_count(const float* adj, int mb, int A, int* row_nnz, int* col_nnz, bmp_stream_t stream);
+int bmp_dense_to_csr(const float* adj, int mb, int A, const int* rowmap, const int* ptr, int transposed, int* col, float* val,
+                     bmp_stream_t stream);
+
 /* ---- link predictor tail: MLP (models/mlp.py:20-45: Linear -> relu -> ... -> Linear on [g1 | g2], train_binary.py:98-101)
  * and sigmoid cross entropy (chainer.functions.sigmoid_cross_entropy, train_ddi_modify.py:285) ----
  * x = [x1 (B x d1) | x2 (B x d2)] (x2 NULL when d2 = 0); dims[0..nl] layer widths (dims[0] = d1 + d2 <= 1024, the others
