@@ -440,36 +440,83 @@ class PReadoutFn(Function):
         require_rows(h, "readout: h")
         _check_pb(pb, h)
         N, d = h.shape
-        d0 = h0.shape[1]
+        d0 = 0 if h0 is None else h0.shape[1]
         ctx.state = state
         WT = W["WT"]
         o = WT.shape[1] // 2
         ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
         g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
-        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(W["b"]), act_j, ptr(pb.row_w),
+        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(W.get("b")), act_j, ptr(pb.row_w),
                                 ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()),
               "bmp_readout_fwd")
-        ctx.save_for_backward(h, h0, ij)
+        ctx.save_for_backward(h, ij, *([h0] if h0 is not None else []))
         ctx.pb, ctx.W, ctx.G, ctx.act_j, ctx.o = pb, W, G, act_j, o
         return g
 
     @staticmethod
     def backward(ctx, dg):
         L = _lib.lib()
-        h, h0, ij = ctx.saved_tensors
+        sv = ctx.saved_tensors
+        h, ij = sv[0], sv[1]
+        h0 = sv[2] if len(sv) > 2 else None
         pb, o, W, G = ctx.pb, ctx.o, ctx.W, ctx.G
         dg = dg.contiguous()
         N, d = h.shape
-        d0 = h0.shape[1]
-        dh, dh0 = torch.empty_like(h), torch.empty_like(h0)
+        d0 = 0 if h0 is None else h0.shape[1]
+        dh = torch.empty_like(h)
+        dh0 = None if h0 is None else torch.empty_like(h0)
         nws = L.bmp_readout_bwd_ws_floats(pb.n_tiles, d, d0, o)
         ws = _ws(nws, h.device)
         first = _first_write(ctx.state, "ro")
         dWT = G["dWT"] if first else torch.empty_like(G["dWT"])
-        db = G["db"] if first else torch.empty_like(G["db"])
+        db = None if G.get("db") is None else (G["db"] if first else torch.empty_like(G["db"]))
         check(L.bmp_readout_bwd(ptr(dg), ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(W["Wnat"]), ptr(ij), ctx.act_j,
                                 ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0),
                                 ptr(dWT), ptr(db), ptr(ws), nws, stream()), "bmp_readout_bwd")
         if not first:
-            G["dWT"].add_(dWT); G["db"].add_(db)
+            G["dWT"].add_(dWT)
+            if db is not None:
+                G["db"].add_(db)
         return dh, dh0, None, None, None, None, None
+
+
+class PMsgFn(Function):
+    """MsgFn (message / RelGCN layer) on prepared weights.  W: WT, bE, WsT, bs, Wnat, Ws; G: dWT, dbE, dWsT, dbs."""
+
+    @staticmethod
+    def forward(ctx, x, pb, W, G, state, gkey, act):
+        L = _lib.lib()
+        require_rows(x, "msg: x")
+        _check_pb(pb, x)
+        d_in, d_out = x.shape[1], W["WT"].shape[1]
+        N = x.shape[0]
+        f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=x.device)
+        agg, wdeg, out = f(N, 4 * d_in), f(N, 4), f(N, d_out)
+        check(L.bmp_msg_fwd(ptr(x), d_in, pb.n_tiles, d_in, d_out, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+                            ptr(W["WT"]), ptr(W["bE"]), ptr(W.get("WsT")), ptr(W.get("bs")), act, ptr(agg), ptr(wdeg), ptr(out),
+                            d_out, stream()), "bmp_msg_fwd")
+        ctx.save_for_backward(x, agg, wdeg, out)
+        ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, agg, wdeg, out = ctx.saved_tensors
+        pb, W, G = ctx.pb, ctx.W, ctx.G
+        dout = dout.contiguous()
+        N, d_out = dout.shape
+        d_in = x.shape[1]
+        dx = torch.empty(N, d_in, dtype=torch.float32, device=x.device)
+        first = _first_write(ctx.state, ctx.gkey)
+        T = G if first else {k: torch.empty_like(v) for k, v in G.items()}
+        nws = L.bmp_msg_bwd_ws_floats(pb.n_tiles, d_in, d_out)
+        ws = _ws(nws, x.device)
+        check(L.bmp_msg_bwd(ptr(dout), d_out, ptr(out), d_out, ctx.act, ptr(x), d_in, pb.n_tiles, d_in, d_out,
+                            ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat"]), ptr(W.get("Ws")), ptr(agg),
+                            ptr(wdeg), ptr(dx), ptr(T["dWT"]), ptr(T["dbE"]), ptr(T.get("dWsT")), ptr(T.get("dbs")), ptr(ws), nws,
+                            stream()), "bmp_msg_bwd")
+        if not first:
+            for k in G:
+                G[k].add_(T[k])
+        return dx, None, None, None, None, None, None

@@ -123,9 +123,62 @@ class RelGCN(nn.Module):
         self.out_dim, self.hidden_dim, self.n_layers = out_channels, ch_list[-1], len(ch_list) - 1
         self.atoms = None
 
+    # ---- layout plan protocol (bmp/plan.py) ----
+    def plannable(self) -> bool:
+        return True
+
+    def primary_layouts(self):
+        out = {"embed.W": self.embed.W}
+        for l, conv in enumerate(self.rgcn_convs):
+            out[f"c{l}.WT"], out[f"c{l}.bE"] = message_kernel_weights(conv.graph_linear_edge)
+            out[f"c{l}.WsT"] = conv.graph_linear_self.W.t().contiguous()
+            out[f"c{l}.bs"] = conv.graph_linear_self.b
+        ro = self.rgcn_readout
+        out["ro.WT"] = torch.cat((ro.i_layer.W.t(), ro.j_layer.W.t()), dim=1).contiguous()
+        return out
+
+    def prepared_layouts(self):
+        p = self.primary_layouts()
+        out = dict(p)
+        for l in range(len(self.rgcn_convs)):
+            out[f"c{l}.Wnat"] = p[f"c{l}.WT"].t().contiguous()
+            out[f"c{l}.Ws"] = p[f"c{l}.WsT"].t().contiguous()
+        out["ro.Wnat"] = p["ro.WT"].t().contiguous()
+        return out
+
+    def gk_spec(self):
+        spec = {"embed.dW": tuple(self.embed.W.shape)}
+        for l, conv in enumerate(self.rgcn_convs):
+            di, do = conv.in_channels, conv.out_channels
+            spec.update({f"c{l}.dWT": (4 * di, do), f"c{l}.dbE": (4, do), f"c{l}.dWsT": (di, do), f"c{l}.dbs": (do,)})
+        spec["ro.dWT"] = (self.hidden_dim, 2 * self.out_dim)
+        return spec
+
+    def primary_grads(self, gk):
+        out = {"embed.W": [gk["embed.dW"]], "ro.WT": [gk["ro.dWT"]]}
+        for l in range(len(self.rgcn_convs)):
+            for a, b in (("WT", "dWT"), ("bE", "dbE"), ("WsT", "dWsT"), ("bs", "dbs")):
+                out[f"c{l}.{a}"] = [gk[f"c{l}.{b}"]]
+        return out
+
+    def _forward_fast(self, pb, fast):
+        P, G, state, tape = fast
+        x = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
+        pbs = rescale_adj(pb) if self.scale_adj else pb
+        for l in range(len(self.rgcn_convs)):
+            W = {k: P[f"c{l}.{k}"] for k in ("WT", "bE", "WsT", "bs", "Wnat", "Ws")}
+            Gl = {k: G[f"c{l}.{k}"] for k in ("dWT", "dbE", "dWsT", "dbs")}
+            x = Fn.PMsgFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
+        self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
+        return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"]), dict(dWT=G["ro.dWT"]),
+                                   Fn.ACT["tanh"], state)
+
     def forward(self, h, adj=None):
         """models/relgcn.py:61-73."""
         pb = as_packed(h, adj, self.embed.W.device)
+        fast = getattr(self, "_fast", None)
+        if fast is not None:
+            return self._forward_fast(pb, fast)
         x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
         pbs = rescale_adj(pb) if self.scale_adj else pb
         for conv in self.rgcn_convs:

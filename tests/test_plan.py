@@ -28,11 +28,13 @@ def test_plan_tables_match_layout_code(tying, n_layers):
     enc = GGNN(out_dim=12, hidden_dim=8, n_layers=n_layers, weight_tying=tying)
     att = NieFineCoattention(hidden_dim=8, out_dim=12, head=3, activation="tanh")
     pool = PoolingFineCoattention(hidden_dim=8, out_dim=12)
+    from bmp.relgcn import RelGCN
+    rel = RelGCN(out_channels=12, ch_list=[8, 16, 8])
     with torch.no_grad():
-        for m in (enc, att, pool):
+        for m in (enc, att, pool, rel):
             for p in m.parameters():
                 p.copy_(torch.randn_like(p))
-    mods = [("graph_conv.", enc), ("attn.", att), ("pool.", pool)]
+    mods = [("graph_conv.", enc), ("attn.", att), ("pool.", pool), ("rel.", rel)]
     names, shapes, flat = _flat_of(mods)
     plan = LayoutPlan(mods, names, shapes, "cpu")
     # (i) prepare == the layout functions, bit for bit
@@ -66,8 +68,8 @@ def test_gather_sum_host_semantics():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("attn", ["nie", "pool"])
-def test_planned_step_equals_eager_step(attn):
+@pytest.mark.parametrize("attn,encoder", [("nie", "ggnn"), ("pool", "ggnn"), ("nie", "relgcn"), ("parallel", "relgcn")])
+def test_planned_step_equals_eager_step(attn, encoder):
     from bmp import packed, synth
     from bmp.dp import FlatAdam
     from bmp.predictor import build_pair_predictor
@@ -78,7 +80,8 @@ def test_planned_step_equals_eager_step(attn):
     pb = packed.pack_from_store(ms, [i1, i2], device=dev)
     t = (torch.arange(16, device=dev) % 2).int().view(-1, 1)
     torch.manual_seed(1)
-    model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=3, attn=attn, head=4).to(dev)
+    model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=3, attn=attn, head=4 if attn != "parallel" else 1,
+                                 encoder=encoder).to(dev)
     # eager: module parameters, autograd through every layout op
     y = model(pb)
     model.loss(y, t).backward()
@@ -88,7 +91,7 @@ def test_planned_step_equals_eager_step(attn):
     # planned: flat buffer, two gather launches
     opt = FlatAdam(model, alpha=1e-3)
     y2 = opt.functional_forward(pb)
-    assert opt.plan is not None and {"graph_conv.", "attn."} <= set(opt.plan.P)
+    assert opt.plan is not None and "graph_conv." in opt.plan.P and (attn == "parallel" or "attn." in opt.plan.P)
     model.loss(y2, t).backward()
     opt.collect_grads()
     assert torch.equal(y2.detach(), y_eager)
