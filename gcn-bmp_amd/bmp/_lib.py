@@ -50,6 +50,8 @@ SIGNATURES = {
     "bmp_rowbcast_bwd": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "bmp_rowdot_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "bmp_rowdot_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "bmp_rowcorr_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _P]),
+    "bmp_rowcorr_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "bmp_dense_count": (_I, [_P, _I, _I, _P, _P, _P]),
     "bmp_dense_to_csr": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P]),
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

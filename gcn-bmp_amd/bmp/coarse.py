@@ -1,5 +1,5 @@
 """Coarse (atom x molecule-vector) co-attention modules with the reference's signatures:
-ParallelCoattention (parallel_coattention.py:12-84), AlternatingCoattention
+ParallelCoattention (parallel_coattention.py:12-84), CircularParallelCoattention (:87-187), AlternatingCoattention
 (alternating_coattention.py:11-86), GlobalCoattention (global_coattention.py:12-73) and
 NeuralCoattention (neural_coattention.py:11-71).
 
@@ -128,6 +128,32 @@ class RowDotFn(Function):
         return dx, du, ds0, None, None, None
 
 
+class RowCorrFn(Function):
+    """e[r] = circular correlation of row a[r] with q[mol(r)] (parallel_coattention.py:162-187)."""
+
+    @staticmethod
+    def forward(ctx, a, q, row0, nrows):
+        L = _lib.lib()
+        a, q = a.contiguous(), q.contiguous()
+        N, o = a.shape
+        if q.shape != (row0.numel(), o):
+            raise ValueError(f"circular correlation: molecule vectors {tuple(q.shape)} vs rows of width {o}")
+        e = torch.zeros(N, o, dtype=torch.float32, device=a.device)
+        check(L.bmp_rowcorr_fwd(ptr(a), o, ptr(q), ptr(row0), ptr(nrows), row0.numel(), ptr(e), stream()), "bmp_rowcorr_fwd")
+        ctx.save_for_backward(a, q, row0, nrows)
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        L = _lib.lib()
+        a, q, row0, nrows = ctx.saved_tensors
+        de = de.contiguous()
+        da, dq = torch.zeros_like(a), torch.empty_like(q)
+        check(L.bmp_rowcorr_bwd(ptr(de), ptr(a), a.shape[1], ptr(q), ptr(row0), ptr(nrows), row0.numel(), ptr(da), ptr(dq),
+                                stream()), "bmp_rowcorr_bwd")
+        return da, dq, None, None
+
+
 def _mol_linear(q: torch.Tensor, WT: torch.Tensor, b, act: int = 0) -> torch.Tensor:
     """Linear on a [M x k] matrix of molecule vectors through the row GEMM (rows padded to the tile size)."""
     R = _lib.lib().bmp_tile_rows()
@@ -240,6 +266,33 @@ class ParallelCoattention(nn.Module):
         e = _ACT[self.activation](side.dot(side.X, u, s0))                   # parallel_coattention.py:77
         J = LinearRowsFn.apply(side.X, self.j_layer.W.t(), self.j_layer.b, 0)
         return side.pool(e[:, None], J)                                      # :45-49 (no softmax)
+
+    def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
+        return _run(self, atoms_1, g_1, atoms_2, g_2)
+
+
+class CircularParallelCoattention(nn.Module):
+    """parallel_coattention.py:87-187: gate_k = act(circular correlation of j_layer(atom) with the OTHER molecule's
+    readout vector), compact = sum over atoms of gate * j_layer(atom).  Only j_layer has parameters; ``weight_tying`` is
+    accepted and unused, as in the reference (:95-99)."""
+
+    def __init__(self, hidden_dim, out_dim, activation="tanh", weight_tying=True):
+        super().__init__()
+        self.j_layer = Linear(hidden_dim, out_dim)
+        self.hidden_dim, self.out_dim, self.head, self.weight_tying = hidden_dim, out_dim, out_dim, weight_tying
+        self.activation = getattr(activation, "__name__", activation) if callable(activation) else activation
+        self.untied = False
+
+    def query(self, side, g_1, g_2):
+        return torch.cat((g_2, g_1), dim=0)
+
+    def query_single(self, other_side, g_other):
+        return g_other
+
+    def _side(self, side, q, focus):
+        J = LinearRowsFn.apply(side.X, self.j_layer.W.t(), self.j_layer.b, 0)           # :115, :129
+        e = _ACT[self.activation](RowCorrFn.apply(J, q, side.row0, side.nrows))           # :156
+        return side.pool(e, J)                                                            # :119-121
 
     def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
         return _run(self, atoms_1, g_1, atoms_2, g_2)

@@ -132,7 +132,8 @@ class NieCoattnFn(Function):
         ZW1, ZW2 = ZW1T.t().contiguous(), ZW2T.t().contiguous()
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         dX1, dX2 = f(*X1.shape), f(*X2.shape)
-        dWbT, dZW1T, dZW2T, dzb, dwa = f(d, d), f(d, ZC), f(d, ZC), f(ZC), f(2 * H + 1)
+        dWbT, dZW1T, dZW2T, dwa = f(d, d), f(d, ZC), f(d, ZC), f(2 * H + 1)
+        dzb = f(2, ZC) if mode & 2 else f(ZC)
         nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
         ws = _ws(nws, dev)
         check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1),
@@ -285,6 +286,119 @@ class NieFineCoattention(_FinePlanMixin, nn.Module):
         WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = self._kernel_weights()
         return NieCoattnFn.apply(X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cb, w1, w2, meta, self.hidden_dim,
                                  self.out_dim, self.head, ACT[self.activation])
+
+
+class _DeepNie(NieFineCoattention):
+    """models/coattention/nie_coattention.py:13-309 (Deep / VeryDeep / ExtremeDeep): the Nie computation whose head and
+    j projections act on ``prev_lt`` chains of the atoms -- n_lt affine layers per side with NO activation between them
+    (:54-59, :155-163) -- while the energy C still sees the original atoms (:47).  A chain of affine maps is one
+    affine map, so the chain is folded into the projection operands here (d x d products, done by the framework so
+    that autograd carries the gradients back to every layer) and the pair kernels run unchanged, with one bias row
+    per side.  Rounding differs from the layer-by-layer evaluation at the 1e-6 level."""
+    n_lt_layers = 1
+    single_layer_names = False
+
+    def __init__(self, hidden_dim, out_dim, head, activation="identity"):
+        super().__init__(hidden_dim, out_dim, head, activation)
+        d = hidden_dim
+        if self.single_layer_names:                                            # nie_coattention.py:27-28
+            self.prev_lt_layer_1, self.prev_lt_layer_2 = Linear(d, d), Linear(d, d)
+        else:                                                                  # :122-129, :225-232
+            self.prev_lt_layers_1 = nn.ModuleList([Linear(d, d) for _ in range(self.n_lt_layers)])
+            self.prev_lt_layers_2 = nn.ModuleList([Linear(d, d) for _ in range(self.n_lt_layers)])
+
+    def _chains(self):
+        if self.single_layer_names:
+            return [self.prev_lt_layer_1], [self.prev_lt_layer_2]
+        return list(self.prev_lt_layers_1), list(self.prev_lt_layers_2)
+
+    def plannable(self) -> bool:
+        return False                     # the folded operands are products of parameters, not a 0/1 map of them
+
+    @staticmethod
+    def _fold(layers):
+        """x -> layers[-1](...layers[0](x)) as (A^T [d x d], c [d]): row form x A^T + c."""
+        AT, c = None, None
+        for lin in layers:
+            WT = lin.W.t()
+            AT = WT if AT is None else AT @ WT
+            c = lin.b if c is None else c @ WT + lin.b
+        return AT, c
+
+    def _kernel_weights(self):
+        d, o, H = self.hidden_dim, self.out_dim, self.head
+        ZC = _lib.lib().bmp_coattn_zcols(o, H)
+        E = self.energy_layer
+        dev, dt = E.W.device, E.W.dtype
+        WbT = E.W[:, :, 0].t()
+        pad = torch.zeros(d, ZC - o - H - 1, device=dev, dtype=dt)
+        ZW, zb = [], []
+        ch1, ch2 = self._chains()
+        for layers, lt, V in ((ch1, self.lt_layer_1, E.V1), (ch2, self.lt_layer_2, E.V2)):
+            AT, c = self._fold(layers)
+            P = torch.cat((self.j_layer.W.t(), lt.W.t()), dim=1)              # [d x (o + H)] on the transformed atoms
+            ZW.append(torch.cat((AT @ P, V, pad), dim=1))
+            zb.append(torch.cat((c @ P + torch.cat((self.j_layer.b, torch.zeros(H, device=dev, dtype=dt))),
+                                 torch.zeros(ZC - o - H, device=dev, dtype=dt))))
+        return WbT, ZW[0], ZW[1], torch.stack(zb), self.attention_layer_1.W[0], self.attention_layer_2.W[0], E.b
+
+    def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
+        if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
+            raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
+        WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = self._kernel_weights()
+        return NieCoattnFn.apply(X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cb, w1, w2, meta, self.hidden_dim,
+                                 self.out_dim, self.head, ACT[self.activation], 2)
+
+
+class DeepNieFineCoattention(_DeepNie):
+    """nie_coattention.py:13-102; the reference names the single layers prev_lt_layer_{1,2}."""
+    n_lt_layers = 1
+    single_layer_names = True
+
+
+class VeryDeepNieFineCoattention(_DeepNie):
+    """nie_coattention.py:105-205."""
+    n_lt_layers = 2
+
+
+class ExtremeDeepNieFineCoattention(_DeepNie):
+    """nie_coattention.py:208-309."""
+    n_lt_layers = 3
+
+
+class FourierFineCoattention(NieFineCoattention):
+    """models/coattention/nie_coattention.py:399-513: the Nie computation with the energy taken between the discrete
+    Fourier transforms (over the feature axis, functions.fft :507-515) of the atom states:
+    C = act(Bilinear(Re F a1, Re F a2) + Bilinear(Im F a1, Im F a2)) (:489), one Bilinear link called twice, so its
+    linear terms and bias enter twice.  With the real DFT matrices Cm[n][k] = cos(2 pi n k / d), Sm = -sin(.) this is
+    the ordinary bilinear energy with W' = Cm W Cm + Sm W Sm, V' = (Cm + Sm) V, b' = 2 b: the transform is folded
+    into the energy operands (by the framework, so autograd returns the gradients to W, V1, V2, b) and the pair kernels
+    run unchanged -- instead of 2 FFTs per atom and two (mb N1 N2, d) Bilinear calls per pair."""
+
+    def plannable(self) -> bool:
+        return False                     # the folded operands are not a 0/1 map of the parameters
+
+    def _dft(self, dev, dt):
+        d = self.hidden_dim
+        key = (str(dev), dt)
+        if getattr(self, "_dft_cache", None) is None or self._dft_cache[0] != key:
+            k = torch.arange(d, dtype=torch.float64)
+            ang = 2.0 * math.pi * ((k[:, None] * k[None, :]) % d) / d
+            self._dft_cache = (key, torch.cos(ang).to(device=dev, dtype=dt), (-torch.sin(ang)).to(device=dev, dtype=dt))
+        return self._dft_cache[1], self._dft_cache[2]
+
+    def _kernel_weights(self):
+        WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = super()._kernel_weights()
+        E = self.energy_layer
+        Cm, Sm = self._dft(E.W.device, E.W.dtype)
+        W = E.W[:, :, 0]
+        Wf = Cm @ W @ Cm + Sm @ W @ Sm
+        o, H = self.out_dim, self.head
+        CS = Cm + Sm
+        ZW1T = torch.cat((ZW1T[:, :o + H], CS @ E.V1, ZW1T[:, o + H + 1:]), dim=1)
+        ZW2T = torch.cat((ZW2T[:, :o + H], CS @ E.V2, ZW2T[:, o + H + 1:]), dim=1)
+        return Wf.t(), ZW1T, ZW2T, zb, wa1, wa2, 2.0 * cb
 
 
 class VQAParallelCoattention(NieFineCoattention):

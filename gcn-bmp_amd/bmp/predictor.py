@@ -89,12 +89,23 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
     if attn in ("nie", "vqa"):
         from .coattention import NieFineCoattention
         a = NieFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
+    elif attn in ("deep", "very-deep", "extreme-deep"):                         # train_binary.py:229-247
+        from . import coattention as C
+        cls = {"deep": C.DeepNieFineCoattention, "very-deep": C.VeryDeepNieFineCoattention,
+               "extreme-deep": C.ExtremeDeepNieFineCoattention}[attn]
+        a = cls(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
+    elif attn == "fourier":                                                      # train_binary.py:249-252
+        from .coattention import FourierFineCoattention
+        a = FourierFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
     elif attn == "pool":
         from .coattention import PoolingFineCoattention
         a = PoolingFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim)       # train_binary.py:210-212
     elif attn == "parallel":
         from .coarse import ParallelCoattention
         a = ParallelCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=1, activation="tanh")   # train_binary.py:200-204
+    elif attn == "circ":                                                         # train_binary.py:206-209
+        from .coarse import CircularParallelCoattention
+        a = CircularParallelCoattention(hidden_dim=hidden_dim, out_dim=out_dim, activation="tanh")
     elif attn == "alternating":
         from .coarse import AlternatingCoattention
         a = AlternatingCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, weight_tying=True)

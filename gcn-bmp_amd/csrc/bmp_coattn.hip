@@ -606,6 +606,7 @@ extern "C" int bmp_coattn_zcols(int o, int H) { return (o + H + 1 + 7) & ~7; }
 
 // Forward.  WbT [d x d] = W (bilinear form, [p][q]) so that Q2 = X2 . W^T uses it K-major as [q][p]:
 // pass WbT[q*d + p] = W[p][q].  ZW1T/ZW2T [d x ZC] K-major columns [Wj^T | Wl_k^T | V_k | 0]; zb [ZC] = [bj | 0].
+// mode bit 1 (value 2): one bias row per side, zb / dzb are [2 x ZC] (the Deep* variants, whose folded projections differ by side).
 extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act, int mode,
                                   const float* w1, const int* r1, const int* n1, const float* w2, const int* r2,
                                   const int* n2, const long long* coff, int B, const int* order, int n32, int n64, int n96,
@@ -623,7 +624,7 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         g[0].nsrc = 1; g[0].Nout = d; g[0].Y = Q2; g[0].ldy = d;
         for (int s = 0; s < 2; ++s) {
             g[1 + s].s[0] = RGSrc{s == 0 ? X1 : X2, nullptr, s == 0 ? ZW1T : ZW2T, d, 0, ZC, d};
-            g[1 + s].nsrc = 1; g[1 + s].Nout = ZC; g[1 + s].Y = s == 0 ? Z1 : Z2; g[1 + s].ldy = ZC; g[1 + s].bias = zb;
+            g[1 + s].nsrc = 1; g[1 + s].Nout = ZC; g[1 + s].Y = s == 0 ? Z1 : Z2; g[1 + s].ldy = ZC; g[1 + s].bias = zb + ((mode & 2) && s ? ZC : 0);
         }
         const int nt[3] = {n_tiles2, n_tiles1, n_tiles2};
         if ((rc = bmp_launch_rowgemm_multi(g, nt, 3, st))) return rc;
@@ -633,7 +634,7 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
-    a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode; a.order = order;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode & 1; a.order = order;
     a.Cbuf = Cbuf; a.H1 = H1; a.H2 = H2; a.al1 = al1; a.al2 = al2; a.out1 = out1; a.out2 = out2;
     // one launch per size class: LDS (and so the workgroups per CU) follows the pairs' actual sizes
     const int cnt[4] = {n32, n64, n96, n128};
@@ -707,7 +708,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2;
-    a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode; a.order = order;
+    a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode & 1; a.order = order;
     a.Cbuf = const_cast<float*>(Cbuf); a.H1 = const_cast<float*>(H1); a.H2 = const_cast<float*>(H2);
     a.al1 = const_cast<float*>(al1); a.al2 = const_cast<float*>(al2);
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
@@ -741,7 +742,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
         // with the two GEMMs that read those arrays anyway (the second reduction accumulates into the first's result)
         const WGArgs g[3] = {WGArgs{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0, nullptr, 0, nullptr},
                              WGArgs{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0, dzb, 0, nullptr},
-                             WGArgs{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb, 1, nullptr}};
+                             WGArgs{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb + ((mode & 2) ? ZC : 0), (mode & 2) ? 0 : 1, nullptr}};
         if (d <= 128 && d >= 64 && ZC >= 64) {
             if ((rc = bmp_launch_wgrad_multi(g, 3, slab, st))) return rc;
         } else {

@@ -145,6 +145,64 @@ __global__ __launch_bounds__(256) void k_rowdot_bwd_u(const float* __restrict__ 
     }
 }
 
+// ---- circular correlation of atom rows with their molecule's vector (CircularParallelCoattention,
+// parallel_coattention.py:139-187): e[r][k] = sum_t a[r][t] * q[m][(t + k) mod o].  One workgroup per molecule; q is
+// held twice over in LDS so that the rotation needs no modulo, rows go through LDS ROWS at a time.  The same kernel
+// gives the gradient with respect to the rows: da[r][t] = sum_k de[r][k] * q[m][(t + k) mod o].
+constexpr int RC_ROWS = 4;
+__global__ __launch_bounds__(256) void k_rowcorr(const float* __restrict__ a, int o, const float* __restrict__ q,
+                                                 const int* __restrict__ row0, const int* __restrict__ nrows,
+                                                 float* __restrict__ e) {
+    extern __shared__ float rc_lds[];
+    float* qq = rc_lds;                 // [2 o]
+    float* ar = rc_lds + 2 * o;         // [RC_ROWS][o]
+    const int m = blockIdx.x, r0 = row0[m], nr = nrows[m];
+    for (int k = threadIdx.x; k < 2 * o; k += 256) qq[k] = q[(size_t)m * o + (k >= o ? k - o : k)];
+    for (int rb = 0; rb < nr; rb += RC_ROWS) {
+        const int nb = min(RC_ROWS, nr - rb);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * o; i += 256) ar[i] = a[(size_t)(r0 + rb) * o + i];
+        __syncthreads();
+        for (int k = threadIdx.x; k < o; k += 256) {
+            float acc[RC_ROWS] = {};
+            for (int t = 0; t < o; ++t) {
+                const float qv = qq[t + k];
+#pragma unroll
+                for (int j = 0; j < RC_ROWS; ++j) acc[j] += ar[j * o + t] * qv;     // rows past nb read stale LDS, never stored
+            }
+            for (int j = 0; j < nb; ++j) e[(size_t)(r0 + rb + j) * o + k] = acc[j];
+        }
+    }
+}
+
+// dq[m][s] = sum_rows sum_t a[r][t] * de[r][(s - t) mod o]
+__global__ __launch_bounds__(256) void k_rowcorr_bwd_q(const float* __restrict__ a, const float* __restrict__ de, int o,
+                                                       const int* __restrict__ row0, const int* __restrict__ nrows,
+                                                       float* __restrict__ dq) {
+    extern __shared__ float rc_lds[];
+    float* dd = rc_lds;                 // [2 o]: de[r] twice over
+    float* ar = rc_lds + 2 * o;         // [o]
+    const int m = blockIdx.x, r0 = row0[m], nr = nrows[m];
+    float acc[4] = {};                  // o <= 1024
+    for (int r = r0; r < r0 + nr; ++r) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2 * o; k += 256) dd[k] = de[(size_t)r * o + (k >= o ? k - o : k)];
+        for (int k = threadIdx.x; k < o; k += 256) ar[k] = a[(size_t)r * o + k];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s_ = threadIdx.x + i * 256;
+            if (s_ < o)
+                for (int t = 0; t < o; ++t) acc[i] += ar[t] * dd[s_ - t + o];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s_ = threadIdx.x + i * 256;
+        if (s_ < o) dq[(size_t)m * o + s_] = acc[i];
+    }
+}
+
 static inline int seg_blocks(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -219,6 +277,30 @@ extern "C" int bmp_rowdot_bwd(const float* ds, const float* x, int d, const floa
     hipLaunchKernelGGL(k_rowdot_bwd_x, dim3(seg_blocks((size_t)N * d)), dim3(256), 0, st, ds, u, d, row_mol, N, dx);
     BMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_rowdot_bwd_u, dim3(n_mols), dim3(256), 0, st, ds, x, d, mol_row0, mol_nrows, du, ds0);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Circular correlation rows x molecule vector.  a, e [N x o] packed rows, q [n_mols x o]; rows outside every molecule are
+// not written (callers weight them with 0).
+extern "C" int bmp_rowcorr_fwd(const float* a, int o, const float* q, const int* mol_row0, const int* mol_nrows, int n_mols,
+                               float* e, hipStream_t st) {
+    BMP_REQUIRE(n_mols > 0 && o > 0 && o <= 1024);
+    hipLaunchKernelGGL(k_rowcorr, dim3(n_mols), dim3(256), (size_t)(2 + RC_ROWS) * o * sizeof(float), st, a, o, q, mol_row0,
+                       mol_nrows, e);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// de [N x o] -> da [N x o] (rows of molecules only) and dq [n_mols x o] (written).
+extern "C" int bmp_rowcorr_bwd(const float* de, const float* a, int o, const float* q, const int* mol_row0,
+                               const int* mol_nrows, int n_mols, float* da, float* dq, hipStream_t st) {
+    BMP_REQUIRE(n_mols > 0 && o > 0 && o <= 1024);
+    hipLaunchKernelGGL(k_rowcorr, dim3(n_mols), dim3(256), (size_t)(2 + RC_ROWS) * o * sizeof(float), st, de, o, q, mol_row0,
+                       mol_nrows, da);
+    BMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rowcorr_bwd_q, dim3(n_mols), dim3(256), (size_t)3 * o * sizeof(float), st, a, de, o, mol_row0,
+                       mol_nrows, dq);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -1,2 +1,3 @@
 from bmp.coattention import NieFineCoattention, VQAParallelCoattention, PoolingFineCoattention  # noqa: F401  (models/coattention/__init__.py)
-from bmp.coarse import ParallelCoattention, AlternatingCoattention, GlobalCoattention, NeuralCoattention  # noqa: F401
+from bmp.coattention import DeepNieFineCoattention, VeryDeepNieFineCoattention, ExtremeDeepNieFineCoattention, FourierFineCoattention  # noqa: F401
+from bmp.coarse import ParallelCoattention, CircularParallelCoattention, AlternatingCoattention, GlobalCoattention, NeuralCoattention  # noqa: F401

@@ -137,6 +137,13 @@ int bmp_rowdot_fwd(const float* x, int d, const float* u, const float* s0, const
                    bmp_stream_t stream);
 int bmp_rowdot_bwd(const float* ds, const float* x, int d, const float* u, const int* row_mol, const int* mol_row0,
                    const int* mol_nrows, int n_mols, int N, float* dx, float* du, float* ds0, bmp_stream_t stream);
+/* CircularParallelCoattention.circular_correlation (models/coattention/parallel_coattention.py:162-187) of every atom
+ * row with its molecule's vector: e[r][k] = sum_t a[r][t] * q[mol(r)][(t + k) mod o].  a, e, de, da [N x o] packed
+ * rows (rows of no molecule are not written), q, dq [n_mols x o]. */
+int bmp_rowcorr_fwd(const float* a, int o, const float* q, const int* mol_row0, const int* mol_nrows, int n_mols, float* e,
+                    bmp_stream_t stream);
+int bmp_rowcorr_bwd(const float* de, const float* a, int o, const float* q, const int* mol_row0, const int* mol_nrows,
+                    int n_mols, float* da, float* dq, bmp_stream_t stream);
 
 /* Fine-grained co-attention -- NieFineCoattention.__call__ + compute_attention
  * models/coattention/nie_coattention.py:335-396 (VQAParallelCoattention

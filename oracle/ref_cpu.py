@@ -245,15 +245,39 @@ def fine_energy(p: Params, prefix: str, atoms_1: Tensor, atoms_2: Tensor, activa
     return ACT[activation](e).reshape(mb, n2, n1)
 
 
+def fourier_energy(p: Params, prefix: str, atoms_1: Tensor, atoms_2: Tensor, activation: str) -> Tensor:
+    """FourierFineCoattention.compute_attention(query=atoms_2, key=atoms_1), nie_coattention.py:460-505: functions.fft
+    of (x, 0) along the last axis (:507-515), every (query, key) combination tiled out, then
+    act(energy_layer(key_real, query_real) + energy_layer(key_imag, query_imag)) (:489) -- the same Bilinear link
+    twice, so V1, V2 and b are applied twice."""
+    mb, n2, hid = atoms_2.shape
+    n1 = atoms_1.shape[1]
+    fq, fk = torch.fft.fft(atoms_2, dim=-1), torch.fft.fft(atoms_1, dim=-1)
+    til_q = lambda x: x[:, :, None, :].expand(mb, n2, n1, hid).reshape(mb * n2 * n1, hid)
+    til_k = lambda x: x[:, None, :, :].expand(mb, n2, n1, hid).reshape(mb * n2 * n1, hid)
+    E = lambda k, q: bilinear(k, q, p[f"{prefix}energy_layer/W"], p[f"{prefix}energy_layer/V1"],
+                              p[f"{prefix}energy_layer/V2"], p[f"{prefix}energy_layer/b"])
+    e = E(til_k(fk.real), til_q(fq.real)) + E(til_k(fk.imag), til_q(fq.imag))
+    return ACT[activation](e).reshape(mb, n2, n1)
+
+
 def nie_coattention(p: Params, atoms_1: Tensor, atoms_2: Tensor, activation: str = "tanh",
-                    prefix: str = "") -> Tuple[Tensor, Tensor]:
+                    prefix: str = "", n_lt: int = 0, fourier: bool = False) -> Tuple[Tensor, Tensor]:
     """NieFineCoattention.__call__ nie_coattention.py:335-370 (VQAParallelCoattention
     vqa_parallel_coattention.py:42-77 is the same computation).  g_1/g_2 are
-    ignored by the fine family."""
+    ignored by the fine family.
+    n_lt = 1, 2, 3: Deep / VeryDeep / ExtremeDeep NieFineCoattention (:38-75, :137-178, :241-282): after the energy
+    C is taken from the ORIGINAL atoms, each side's atoms pass through its n_lt prev_lt GraphLinear layers (affine, no
+    activation) before the head and j projections."""
     P = lambda k: p[prefix + k]
-    C = fine_energy(p, prefix, atoms_1, atoms_2, activation)        # (mb, N2, N1)
+    C = (fourier_energy if fourier else fine_energy)(p, prefix, atoms_1, atoms_2, activation)        # (mb, N2, N1)
     L_2 = torch.softmax(C, dim=1)                                    # :347
     L_1 = torch.softmax(C.transpose(1, 2), dim=1)                    # :349  (mb, N1, N2)
+    for k in range(n_lt):                                            # :54-59 / :155-163
+        n1 = "prev_lt_layer_1" if n_lt == 1 else f"prev_lt_layers_1/{k}"
+        n2 = "prev_lt_layer_2" if n_lt == 1 else f"prev_lt_layers_2/{k}"
+        atoms_1 = linear(atoms_1, P(n1 + "/W"), P(n1 + "/b"))
+        atoms_2 = linear(atoms_2, P(n2 + "/W"), P(n2 + "/b"))
     lt_1 = linear(atoms_1, P("lt_layer_1/W"))                        # (mb, N1, head)
     lt_2 = linear(atoms_2, P("lt_layer_2/W"))
     H_1 = torch.tanh(lt_1 + torch.bmm(L_1, lt_2))                    # :356-358
@@ -300,6 +324,23 @@ def parallel_coattention(p: Params, atoms_1: Tensor, g_1: Tensor, atoms_2: Tenso
     j1 = linear(atoms_1, P("j_layer/W"), P("j_layer/b"))
     j2 = linear(atoms_2, P("j_layer/W"), P("j_layer/b"))
     return (a1 * j1).sum(dim=1), (a2 * j2).sum(dim=1)
+
+
+def circular_parallel_coattention(p: Params, atoms_1: Tensor, g_1: Tensor, atoms_2: Tensor, g_2: Tensor,
+                                  activation: str = "tanh", prefix: str = "") -> Tuple[Tensor, Tensor]:
+    """CircularParallelCoattention.__call__ parallel_coattention.py:108-160: atoms -> j_layer (:115, :129); the other
+    molecule's vector tiled over the atoms; gate = act(circular_correlation(key=j atoms, query)) (:156, the same
+    fft / conj-product / ifft op sequence as HolE's, :162-187); compact = sum over atoms of gate * j atoms."""
+    P = lambda k: p[prefix + k]
+
+    def attend(query, key):
+        mb, n, o = key.shape
+        q = query[:, None, :].expand(mb, n, o).reshape(mb * n, o)
+        return ACT[activation](circular_correlation(key.reshape(mb * n, o), q)).reshape(mb, n, o)
+
+    j1 = linear(atoms_1, P("j_layer/W"), P("j_layer/b"))
+    j2 = linear(atoms_2, P("j_layer/W"), P("j_layer/b"))
+    return (attend(g_2, j1) * j1).sum(dim=1), (attend(g_1, j2) * j2).sum(dim=1)
 
 
 def alternating_coattention(p: Params, atoms_1: Tensor, g_1: Tensor, atoms_2: Tensor, g_2: Tensor,
@@ -445,6 +486,13 @@ def pair_forward(p: Params, atoms_1: Tensor, adjs_1: Tensor, atoms_2: Tensor, ad
         g1, g2 = pooling_coattention(p, at1, at2, attn_activation, prefix="attn/")
     elif attn == "parallel":
         g1, g2 = parallel_coattention(p, at1, g1, at2, g2, attn_activation, prefix="attn/")
+    elif attn == "circ":
+        g1, g2 = circular_parallel_coattention(p, at1, g1, at2, g2, attn_activation, prefix="attn/")
+    elif attn in ("deep", "very-deep", "extreme-deep"):
+        g1, g2 = nie_coattention(p, at1, at2, attn_activation, prefix="attn/",
+                                 n_lt={"deep": 1, "very-deep": 2, "extreme-deep": 3}[attn])
+    elif attn == "fourier":
+        g1, g2 = nie_coattention(p, at1, at2, attn_activation, prefix="attn/", fourier=True)
     elif attn == "alternating":
         g1, g2 = alternating_coattention(p, at1, g1, at2, g2, prefix="attn/")
     elif attn == "global":
@@ -532,11 +580,14 @@ def init_relgcn(dr: _Draw, prefix: str, out_channels: int, ch_list: Sequence[int
     dr.lin(f"{prefix}rgcn_readout/j_layer", ch_list[-1], out_channels, bias=False)
 
 
-def init_nie(dr: _Draw, prefix: str, hidden_dim: int, out_dim: int, head: int) -> None:
-    """Link tree of nie_coattention.py:323-330 (VQA identical)."""
+def init_nie(dr: _Draw, prefix: str, hidden_dim: int, out_dim: int, head: int, n_lt: int = 0) -> None:
+    """Link tree of nie_coattention.py:323-330 (VQA identical); n_lt > 0: the Deep variants' trees (:24-33, :118-131)."""
     dr.bil(f"{prefix}energy_layer", hidden_dim, hidden_dim, 1)
     dr.lin(f"{prefix}attention_layer_1", head, 1, bias=False)
     dr.lin(f"{prefix}attention_layer_2", head, 1, bias=False)
+    for side in (1, 2):
+        for k in range(n_lt):
+            dr.lin(f"{prefix}prev_lt_layer_{side}" if n_lt == 1 else f"{prefix}prev_lt_layers_{side}/{k}", hidden_dim, hidden_dim)
     dr.lin(f"{prefix}lt_layer_1", hidden_dim, head, bias=False)
     dr.lin(f"{prefix}lt_layer_2", hidden_dim, head, bias=False)
     dr.lin(f"{prefix}j_layer", hidden_dim, out_dim)
@@ -621,6 +672,12 @@ def make_pair_params(seed: int = 777, *, encoder: str = "ggnn", hidden_dim: int 
         init_pooling(dr, "attn/", hidden_dim, out_dim)
     elif attn == "parallel":
         init_parallel(dr, "attn/", hidden_dim, out_dim, 1)
+    elif attn == "circ":
+        dr.lin("attn/j_layer", hidden_dim, out_dim)
+    elif attn in ("deep", "very-deep", "extreme-deep"):
+        init_nie(dr, "attn/", hidden_dim, out_dim, head, n_lt={"deep": 1, "very-deep": 2, "extreme-deep": 3}[attn])
+    elif attn == "fourier":
+        init_nie(dr, "attn/", hidden_dim, out_dim, head)
     elif attn == "alternating":
         init_alternating(dr, "attn/", hidden_dim, out_dim, head)
     elif attn == "global":

@@ -92,9 +92,18 @@ def ggnn_forward(p: Dict[str, Tensor], pb, n_layers: int, weight_tying=True, pre
     return segment_sum(pb, w * gi * gj), h
 
 
-def nie_coattention(p: Dict[str, Tensor], pb, X: Tensor, pair_m1, pair_m2, activation="tanh", prefix=""):
-    """Packed NieFineCoattention with multiplicities (nie_coattention.py:335-396)."""
+def nie_coattention(p: Dict[str, Tensor], pb, X: Tensor, pair_m1, pair_m2, activation="tanh", prefix="", n_lt=0,
+                    fourier=False):
+    """Packed NieFineCoattention with multiplicities (nie_coattention.py:335-396).  n_lt > 0: the Deep variants
+    (:13-309) -- head and j projections act on the prev_lt chain of the atoms, layer by layer as the reference does."""
     P = lambda k: p[prefix + k]
+
+    def chain(x, side):
+        for k in range(n_lt):
+            name = f"prev_lt_layer_{side}" if f"{prefix}prev_lt_layer_{side}/W" in p else f"prev_lt_layers_{side}/{k}"
+            x = x @ P(name + "/W").t() + P(name + "/b")
+        return x
+
     act = {"tanh": torch.tanh, "identity": lambda x: x}[activation]
     W = P("energy_layer/W")[:, :, 0]; V1 = P("energy_layer/V1")[:, 0]; V2 = P("energy_layer/V2")[:, 0]
     cb = P("energy_layer/b")[0]
@@ -104,16 +113,22 @@ def nie_coattention(p: Dict[str, Tensor], pb, X: Tensor, pair_m1, pair_m2, activ
         a, c = int(pair_m1[b]), int(pair_m2[b])
         x1 = X[r0[a]:r0[a] + nr[a]]; w1 = w[r0[a]:r0[a] + nr[a]]
         x2 = X[r0[c]:r0[c] + nr[c]]; w2 = w[r0[c]:r0[c] + nr[c]]
-        C = act((x2 @ W.t()) @ x1.t() + (x1 @ V1)[None, :] + (x2 @ V2)[:, None] + cb)     # (n2, n1)
+        pre = lambda u1, u2: (u2 @ W.t()) @ u1.t() + (u1 @ V1)[None, :] + (u2 @ V2)[:, None] + cb
+        if fourier:          # FourierFineCoattention (:460-505): energy between the DFTs over the feature axis
+            f1, f2 = torch.fft.fft(x1, dim=-1), torch.fft.fft(x2, dim=-1)
+            C = act(pre(f1.real, f2.real) + pre(f1.imag, f2.imag))
+        else:
+            C = act(pre(x1, x2))                                    # (n2, n1)
         E = torch.exp(C - C.max())
         L2 = E / (w2[:, None] * E).sum(dim=0, keepdim=True)        # softmax over i (side-2 atoms) per j
         L1 = E / (w1[None, :] * E).sum(dim=1, keepdim=True)        # softmax over j per i; L1[j,i] = this[i,j]
-        P1 = x1 @ P("lt_layer_1/W").t(); P2 = x2 @ P("lt_layer_2/W").t()
+        y1, y2 = chain(x1, 1), chain(x2, 2)
+        P1 = y1 @ P("lt_layer_1/W").t(); P2 = y2 @ P("lt_layer_2/W").t()
         H1 = torch.tanh(P1 + (L1 * w2[:, None]).t() @ P2)
         H2 = torch.tanh(P2 + (L2 * w1[None, :]) @ P1)
         s1 = (H1 @ P("attention_layer_1/W").t())[:, 0]; s2 = (H2 @ P("attention_layer_2/W").t())[:, 0]
         e1 = torch.exp(s1 - s1.max()); e2 = torch.exp(s2 - s2.max())
         a1 = e1 / (w1 * e1).sum(); a2 = e2 / (w2 * e2).sum()
-        J1 = x1 @ P("j_layer/W").t() + P("j_layer/b"); J2 = x2 @ P("j_layer/W").t() + P("j_layer/b")
+        J1 = y1 @ P("j_layer/W").t() + P("j_layer/b"); J2 = y2 @ P("j_layer/W").t() + P("j_layer/b")
         out1.append(((w1 * a1)[:, None] * J1).sum(0)); out2.append(((w2 * a2)[:, None] * J2).sum(0))
     return torch.stack(out1), torch.stack(out2)

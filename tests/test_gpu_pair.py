@@ -60,6 +60,71 @@ def test_nie_coattention_op(pairs, d, o, act):
         close(gr, p[name].grad, f"grad {name}", floor=floor)
 
 
+@pytest.mark.parametrize("d,o", [(16, 16), (64, 32)])
+def test_fourier_nie_coattention_op(pairs, d, o):
+    """FourierFineCoattention: the product folds the DFT into the energy operands; the restatement transforms the
+    atom states and calls the bilinear form twice (nie_coattention.py:460-505)."""
+    from bmp.coattention import FourierFineCoattention
+    from bmp.ggnn import PackedAtoms
+    from bmp.snapshot import load_param_dict, grad_dict
+    store, i1, i2, pb = pairs
+    pbd = to_dev(pb)
+    B = len(i1)
+    dr = O._Draw(d + 5, torch.float64, 0.2)
+    O.init_nie(dr, "", d, o, 8)
+    p = {k: v.requires_grad_() for k, v in dr.p.items()}
+    g = torch.Generator().manual_seed(d)
+    X = torch.randn(pb.n_rows, d, generator=g, dtype=torch.float64) * (0.5 / d ** 0.5)    # |DFT| ~ sqrt(d) |x|
+    Xr = X.clone().requires_grad_()
+    c1, c2 = PR.nie_coattention(p, pb, Xr, np.arange(B), B + np.arange(B), activation="tanh", fourier=True)
+    w1 = torch.randn(B, o, generator=g, dtype=torch.float64); w2 = torch.randn(B, o, generator=g, dtype=torch.float64)
+    ((c1 * w1).sum() + (c2 * w2).sum()).backward()
+    att = FourierFineCoattention(d, o, 8, activation="tanh").to(dev())
+    load_param_dict(att, p)
+    Xd = X.float().to(dev()).requires_grad_()
+    at = PackedAtoms(Xd, pbd)
+    o1, o2 = att(at, None, at, None)
+    close(o1, c1, "compact_1"); close(o2, c2, "compact_2")
+    ((o1 * w1.float().to(dev())).sum() + (o2 * w2.float().to(dev())).sum()).backward()
+    close(Xd.grad, Xr.grad, "dX")
+    for name, gr in grad_dict(att).items():
+        close(gr, p[name].grad, f"grad {name}")
+
+
+@pytest.mark.parametrize("n_lt,d,o", [(1, 16, 16), (2, 64, 32), (3, 128, 128)])
+def test_deep_nie_coattention_op(pairs, n_lt, d, o):
+    """Deep / VeryDeep / ExtremeDeep NieFineCoattention: the product folds each side's affine chain into the
+    projection operands; the restatement applies the layers one by one (nie_coattention.py:54-59, :155-163)."""
+    from bmp import coattention as C
+    from bmp.ggnn import PackedAtoms
+    from bmp.snapshot import load_param_dict, grad_dict
+    store, i1, i2, pb = pairs
+    pbd = to_dev(pb)
+    B = len(i1)
+    dr = O._Draw(d + n_lt, torch.float64, 0.2)
+    O.init_nie(dr, "", d, o, 8, n_lt=n_lt)
+    p = {k: v.requires_grad_() for k, v in dr.p.items()}
+    g = torch.Generator().manual_seed(d)
+    X = torch.randn(pb.n_rows, d, generator=g, dtype=torch.float64)
+    Xr = X.clone().requires_grad_()
+    c1, c2 = PR.nie_coattention(p, pb, Xr, np.arange(B), B + np.arange(B), activation="tanh", n_lt=n_lt)
+    w1 = torch.randn(B, o, generator=g, dtype=torch.float64); w2 = torch.randn(B, o, generator=g, dtype=torch.float64)
+    ((c1 * w1).sum() + (c2 * w2).sum()).backward()
+    cls = {1: C.DeepNieFineCoattention, 2: C.VeryDeepNieFineCoattention, 3: C.ExtremeDeepNieFineCoattention}[n_lt]
+    att = cls(d, o, 8, activation="tanh").to(dev())
+    load_param_dict(att, p)
+    Xd = X.float().to(dev()).requires_grad_()
+    at = PackedAtoms(Xd, pbd)
+    o1, o2 = att(at, None, at, None)
+    close(o1, c1, "compact_1"); close(o2, c2, "compact_2")
+    ((o1 * w1.float().to(dev())).sum() + (o2 * w2.float().to(dev())).sum()).backward()
+    close(Xd.grad, Xr.grad, "dX")
+    gd = grad_dict(att)
+    assert set(gd) == set(p)
+    for name, gr in gd.items():
+        close(gr, p[name].grad, f"grad {name}")
+
+
 @pytest.mark.parametrize("d,nl,tying", [(16, 2, True), (128, 4, True), (32, 3, False)])
 def test_pair_predictor_matches_dense_oracle(pairs, d, nl, tying):
     from bmp.predictor import build_pair_predictor
@@ -150,7 +215,7 @@ def test_pooling_coattention_pair(pairs, d, act):
     p = {k: v.requires_grad_() for k, v in p.items()}
     a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
     y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn="pool")
-    c = torch.randn(y.shape, dtype=torch.float64)
+    c = torch.randn(y.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(17))
     (y * c).sum().backward()
     model = build_pair_predictor(hidden_dim=d, out_dim=d, n_layers=2, attn="pool").to(dev())
     load_param_dict(model, p)
@@ -162,10 +227,13 @@ def test_pooling_coattention_pair(pairs, d, act):
         if ref is None:
             assert name.startswith(("graph_conv/i_layers", "graph_conv/j_layers")), name
             continue
-        close(gr, ref, f"grad {name}")
+        # the atom weights are a softmax of means of C: a common shift of C nearly cancels, so the energy bias gradient
+        # is a small difference of large sums -- compare it on the scale of the energy layer's other gradients
+        floor = p["attn/energy_layer/V1"].grad.abs().max().item() if name == "attn/energy_layer/b" else 1e-6
+        close(gr, ref, f"grad {name}", floor=floor)
 
 
-@pytest.mark.parametrize("attn", ["parallel", "alternating", "global", "neural"])
+@pytest.mark.parametrize("attn", ["parallel", "circ", "alternating", "global", "neural"])
 @pytest.mark.parametrize("joint", [True, False])
 def test_coarse_coattention_pair(pairs, attn, joint):
     """Coarse (atom x molecule-vector) co-attention family through the pair predictor vs the dense oracle,
@@ -178,7 +246,7 @@ def test_coarse_coattention_pair(pairs, attn, joint):
     p = {k: v.requires_grad_() for k, v in p.items()}
     a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
     y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn=attn)
-    c = torch.randn(y.shape, dtype=torch.float64)
+    c = torch.randn(y.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(17))
     (y * c).sum().backward()
     model = build_pair_predictor(hidden_dim=d, out_dim=d, n_layers=2, attn=attn).to(dev())
     load_param_dict(model, p)
@@ -193,4 +261,32 @@ def test_coarse_coattention_pair(pairs, attn, joint):
         # a bias added right before a softmax has an analytically zero gradient (shift invariance):
         # compare it on the scale of the weight gradient of the same layer
         floor = p["attn/energy_layers_2/0/W"].grad.abs().max().item() if name == "attn/energy_layers_2/0/b" else 1e-6
+        if attn == "circ":       # gate and value both come from j_layer: gradients are sums of o-term products
+            floor = 1e-4 * float(ref.abs().max())
         close(gr, ref, f"grad {name}", floor=floor)
+
+
+@pytest.mark.parametrize("attn", ["deep", "extreme-deep", "fourier"])
+def test_folded_fine_variants_through_the_pair_predictor(pairs, attn):
+    """Deep* / Fourier co-attention inside the whole pair model (encoder gradients included) vs the dense oracle."""
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict, grad_dict
+    store, i1, i2, pb = pairs
+    d = 16
+    p = O.make_pair_params(43, hidden_dim=d, out_dim=d, n_layers=2, attn=attn, dtype=torch.float64)
+    p = {k: v.requires_grad_() for k, v in p.items()}
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn=attn)
+    c = torch.randn(y.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(17))
+    (y * c).sum().backward()
+    model = build_pair_predictor(hidden_dim=d, out_dim=d, n_layers=2, attn=attn).to(dev())
+    load_param_dict(model, p)
+    yd = model(to_dev(pb))
+    close(model.g1, g1, "g1"); close(model.g2, g2, "g2"); close(yd, y, "logits")
+    (yd * c.float().to(dev())).sum().backward()
+    for name, gr in grad_dict(model).items():
+        ref = p[name].grad
+        if ref is None:
+            assert gr is None or float(gr.abs().max()) == 0.0, name
+            continue
+        close(gr, ref, f"grad {name}")

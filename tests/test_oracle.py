@@ -211,3 +211,32 @@ def test_modular_ggnn_untied_takes_first_branch():
     q["update_layers/1/update_layer/U/W"] = torch.randn_like(p["update_layers/1/update_layer/U/W"])
     g1, _ = O.ggnn_modular_forward(q, T(a), T(adj).double(), 2, weight_tying=False)
     assert torch.equal(g0, g1)
+
+
+def test_circular_parallel_against_explicit_rotation_sum():
+    """CircularParallelCoattention (parallel_coattention.py:87-187): the fft form of the oracle against the defining
+    sum gate[k] = tanh(sum_t j[t] * g[(t + k) mod o])."""
+    torch.manual_seed(3)
+    mb, n1, n2, d, o = 3, 5, 4, 6, 8
+    p = {"j_layer/W": torch.randn(o, d, dtype=torch.float64), "j_layer/b": torch.randn(o, dtype=torch.float64)}
+    a1, a2 = torch.randn(mb, n1, d, dtype=torch.float64), torch.randn(mb, n2, d, dtype=torch.float64)
+    g1, g2 = torch.randn(mb, o, dtype=torch.float64), torch.randn(mb, o, dtype=torch.float64)
+    c1, c2 = O.circular_parallel_coattention(p, a1, g1, a2, g2)
+    for atoms, g, c in ((a1, g2, c1), (a2, g1, c2)):
+        J = atoms @ p["j_layer/W"].t() + p["j_layer/b"]
+        ref = torch.zeros(mb, o, dtype=torch.float64)
+        for k in range(o):
+            gate = torch.tanh((J * torch.roll(g, -k, dims=1)[:, None, :]).sum(-1))     # (mb, n)
+            ref[:, k] = (gate * J[:, :, k]).sum(1)
+        assert torch.allclose(c, ref, atol=1e-12)
+
+
+@pytest.mark.parametrize("attn", ["deep", "very-deep", "extreme-deep", "fourier", "circ"])
+def test_pair_forward_with_the_added_coattention_variants(attn):
+    from bmp import synth
+    store = synth.make_store(6, seed=2, n_lo=3, n_hi=9, n_mean=6)
+    a1, j1 = synth.concat_mols(store[:3]); a2, j2 = synth.concat_mols(store[3:])
+    p = O.make_pair_params(5, hidden_dim=8, out_dim=8, n_layers=2, attn=attn, dtype=torch.float64)
+    y, g1, g2 = O.pair_forward(p, torch.from_numpy(a1), torch.from_numpy(j1).double(), torch.from_numpy(a2),
+                               torch.from_numpy(j2).double(), n_layers=2, attn=attn)
+    assert y.shape == (3, 1) and g1.shape == (3, 8) and torch.isfinite(y).all()

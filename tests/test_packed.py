@@ -154,3 +154,32 @@ def test_packed_nie_matches_dense_oracle_with_grads(store):
         assert (x is None) == (y_ is None), n        # the fine family ignores g_1/g_2 (readout unused)
         if x is not None:
             assert torch.allclose(x, y_, rtol=1e-9, atol=1e-11), n
+
+
+@pytest.mark.parametrize("n_lt", [1, 2, 3])
+def test_packed_deep_nie_matches_dense_oracle(store, n_lt):
+    """Deep / VeryDeep / ExtremeDeep NieFineCoattention (nie_coattention.py:13-309): the packed restatement (pad
+    positions as one weighted row) against the dense one on the padded atom states of a real encoder."""
+    p, pb, (a1, j1), (a2, j2) = _setup(store, nl=2)
+    dr = O._Draw(777, torch.float64, 0.2)
+    O.init_nie(dr, "deep/", 8, 8, 8, n_lt=n_lt)
+    p.update(dr.p)
+    _, at1 = O.ggnn_forward(p, T(a1), T(j1).double(), 2, prefix="graph_conv/")
+    _, at2 = O.ggnn_forward(p, T(a2), T(j2).double(), 2, prefix="graph_conv/")
+    g1, g2 = O.nie_coattention(p, at1, at2, prefix="deep/", n_lt=n_lt)
+    _, h = PR.ggnn_forward(p, pb, 2, prefix="graph_conv/")
+    c1, c2 = PR.nie_coattention(p, pb, h, np.arange(7), 7 + np.arange(7), prefix="deep/", n_lt=n_lt)
+    assert torch.allclose(c1, g1, atol=1e-12) and torch.allclose(c2, g2, atol=1e-12)
+
+
+def test_packed_fourier_nie_matches_dense_oracle(store):
+    """FourierFineCoattention (nie_coattention.py:399-513)."""
+    p, pb, (a1, j1), (a2, j2) = _setup(store, nl=2)
+    _, at1 = O.ggnn_forward(p, T(a1), T(j1).double(), 2, prefix="graph_conv/")
+    _, at2 = O.ggnn_forward(p, T(a2), T(j2).double(), 2, prefix="graph_conv/")
+    g1, g2 = O.nie_coattention(p, at1, at2, prefix="attn/", fourier=True)
+    _, h = PR.ggnn_forward(p, pb, 2, prefix="graph_conv/")
+    c1, c2 = PR.nie_coattention(p, pb, h, np.arange(7), 7 + np.arange(7), prefix="attn/", fourier=True)
+    assert torch.allclose(c1, g1, atol=1e-12) and torch.allclose(c2, g2, atol=1e-12)
+    n1, n2 = O.nie_coattention(p, at1, at2, prefix="attn/")
+    assert not torch.allclose(g1, n1, atol=1e-3)                   # and it is not the plain Nie energy
