@@ -108,11 +108,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal switches for a one-GPU box (never set by the driver): all ranks on device 0, collectives over gloo
+    one_device = os.environ.get("BMP_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("BMP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -145,13 +152,14 @@ def main():
     opt = FlatAdam(model, alpha=1e-3)
     opt.broadcast_parameters(0)
 
-    def step(i):
+    def step(i, collective=True):
         pb, t = batches[i % N_DISTINCT_BATCHES]
         y = opt.functional_forward(pb)          # parameters = views of the flat buffer, ONE gradient tensor
         loss = model.loss(y, t)
         loss.backward()
         opt.collect_grads()
-        opt.all_reduce_grads()
+        if collective:                          # the roofline leg below runs on rank 0 alone: no collective there
+            opt.all_reduce_grads()
         opt.step()
         return loss
 
@@ -184,7 +192,7 @@ def main():
         for cls in classes:
             L.bmp_prof_start(cls)
             for i in range(n_prof):
-                step(i)
+                step(i, collective=False)
             torch.cuda.synchronize()
             n = L.bmp_prof_stop(out)
             if n:
