@@ -520,3 +520,80 @@ class PMsgFn(Function):
             for k in G:
                 G[k].add_(T[k])
         return dx, None, None, None, None, None, None
+
+
+def rel_layer_supported(d_in: int, d_out: int) -> bool:
+    return bool(_lib.lib().bmp_relgcn_layer_supported(int(d_in), int(d_out)))
+
+
+def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act):
+    L = _lib.lib()
+    N, d = x.shape
+    out = torch.empty(N, d, dtype=torch.float32, device=x.device)
+    wdeg = torch.empty(N, 4, dtype=torch.float32, device=x.device)
+    check(L.bmp_relgcn_layer_fwd(ptr(x), pb.n_tiles, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
+                                 ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), stream()), "bmp_relgcn_layer_fwd")
+    return out, wdeg
+
+
+def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate):
+    L = _lib.lib()
+    N, d = x.shape
+    dx = torch.empty(N, d, dtype=torch.float32, device=x.device)
+    gda = torch.empty(N, 5 * d, dtype=torch.float32, device=x.device)
+    check(L.bmp_relgcn_layer_bwd(ptr(dout), ptr(out), act, pb.n_tiles, d, ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val),
+                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), stream()), "bmp_relgcn_layer_bwd")
+    nws = L.bmp_relgcn_layer_wgrad_ws_floats(N, d)
+    ws = _ws(nws, x.device)
+    check(L.bmp_relgcn_layer_wgrad(ptr(x), ptr(wdeg), ptr(gda), N, d, ptr(o1), ptr(dbE), ptr(cs), int(accumulate), ptr(ws), nws,
+                                   stream()), "bmp_relgcn_layer_wgrad")
+    return dx
+
+
+class RelLayerFn(Function):
+    """One whole RelGCN layer as ONE fused kernel per tile (models/update/relgcn_update.py:24-44 + models/relgcn.py:71),
+    d_in == d_out in {64, 128}.  Weight layouts as MsgFn: WT [4d x d], bE [4 x d], WsT [d x d], bs [d]."""
+
+    @staticmethod
+    def forward(ctx, x, WT, bE, WsT, bs, pb, act):
+        require_rows(x, "relgcn layer: x")
+        _check_pb(pb, x)
+        d = x.shape[1]
+        if tuple(WT.shape) != (4 * d, d) or tuple(WsT.shape) != (d, d):
+            raise ValueError("relgcn layer: weight shapes do not match x")
+        out, wdeg = _rel_fwd(x, pb, pack_k4(WT), bE.contiguous(), pack_k4(WsT), bs.contiguous(), act)
+        ctx.save_for_backward(x, WT, WsT, out, wdeg)
+        ctx.pb, ctx.act = pb, act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, WT, WsT, out, wdeg = ctx.saved_tensors
+        d = x.shape[1]
+        f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=x.device)
+        o1, dbE, cs = f(d, 5 * d), f(4, d), f(5 * d)
+        dx = _rel_bwd(dout.contiguous(), out, x, wdeg, ctx.pb, pack_k4(WT.t()), pack_k4(WsT.t()), ctx.act, o1, dbE, cs, 0)
+        dWT = o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)        # [k][e*d+c] -> [e*d+k][c]
+        return dx, dWT, dbE, o1[:, 4 * d:], cs[4 * d:], None, None
+
+
+class PRelLayerFn(Function):
+    """RelLayerFn on prepared weights (bmp/plan.py).  W: WTp, bE, WsTp, bs, Wnat_p, Ws_p; G: o1 [d x 5d], dbE, cs [5d]."""
+
+    @staticmethod
+    def forward(ctx, x, pb, W, G, state, gkey, act):
+        require_rows(x, "relgcn layer: x")
+        _check_pb(pb, x)
+        out, wdeg = _rel_fwd(x, pb, W["WTp"], W["bE"], W["WsTp"], W["bs"], act)
+        ctx.save_for_backward(x, out, wdeg)
+        ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, wdeg = ctx.saved_tensors
+        W, G = ctx.W, ctx.G
+        first = _first_write(ctx.state, ctx.gkey)
+        dx = _rel_bwd(dout.contiguous(), out, x, wdeg, ctx.pb, W["Wnat_p"], W["Ws_p"], ctx.act, G["o1"], G["dbE"], G["cs"],
+                      0 if first else 1)
+        return dx, None, None, None, None, None, None

@@ -51,6 +51,8 @@ class RelGCNUpdate(nn.Module):
         """hs + sum_e adj_e (W_e h + b_e) (relgcn_update.py:24-44); ``act`` lets the caller fuse the
         tanh of models/relgcn.py:71 into the same kernel."""
         WT, bE = message_kernel_weights(self.graph_linear_edge)
+        if h.is_cuda and Fn.rel_layer_supported(self.in_channels, self.out_channels):
+            return Fn.RelLayerFn.apply(h, WT, bE, self.graph_linear_self.W.t(), self.graph_linear_self.b, pb, Fn.ACT[act])
         return Fn.MsgFn.apply(h, WT, bE, self.graph_linear_self.W.t(), self.graph_linear_self.b, pb, Fn.ACT[act])
 
 
@@ -137,12 +139,22 @@ class RelGCN(nn.Module):
         out["ro.WT"] = torch.cat((ro.i_layer.W.t(), ro.j_layer.W.t()), dim=1).contiguous()
         return out
 
+    def _fused(self, l) -> bool:
+        """Layer l runs as the fused tile kernel (d_in == d_out in {64, 128}); otherwise bmp_msg_fwd/bwd."""
+        conv = self.rgcn_convs[l]
+        return Fn.rel_layer_supported(conv.in_channels, conv.out_channels)
+
     def prepared_layouts(self):
         p = self.primary_layouts()
         out = dict(p)
         for l in range(len(self.rgcn_convs)):
-            out[f"c{l}.Wnat"] = p[f"c{l}.WT"].t().contiguous()
-            out[f"c{l}.Ws"] = p[f"c{l}.WsT"].t().contiguous()
+            if self._fused(l):
+                WT, WsT = p[f"c{l}.WT"], p[f"c{l}.WsT"]
+                out[f"c{l}.WTp"], out[f"c{l}.WsTp"] = Fn.pack_k4(WT), Fn.pack_k4(WsT)
+                out[f"c{l}.Wnat_p"], out[f"c{l}.Ws_p"] = Fn.pack_k4(WT.t()), Fn.pack_k4(WsT.t())
+            else:
+                out[f"c{l}.Wnat"] = p[f"c{l}.WT"].t().contiguous()
+                out[f"c{l}.Ws"] = p[f"c{l}.WsT"].t().contiguous()
         out["ro.Wnat"] = p["ro.WT"].t().contiguous()
         return out
 
@@ -150,15 +162,26 @@ class RelGCN(nn.Module):
         spec = {"embed.dW": tuple(self.embed.W.shape)}
         for l, conv in enumerate(self.rgcn_convs):
             di, do = conv.in_channels, conv.out_channels
-            spec.update({f"c{l}.dWT": (4 * di, do), f"c{l}.dbE": (4, do), f"c{l}.dWsT": (di, do), f"c{l}.dbs": (do,)})
+            if self._fused(l):
+                spec.update({f"c{l}.o1": (di, 5 * di), f"c{l}.dbE": (4, do), f"c{l}.cs": (5 * di,)})
+            else:
+                spec.update({f"c{l}.dWT": (4 * di, do), f"c{l}.dbE": (4, do), f"c{l}.dWsT": (di, do), f"c{l}.dbs": (do,)})
         spec["ro.dWT"] = (self.hidden_dim, 2 * self.out_dim)
         return spec
 
     def primary_grads(self, gk):
         out = {"embed.W": [gk["embed.dW"]], "ro.WT": [gk["ro.dWT"]]}
-        for l in range(len(self.rgcn_convs)):
-            for a, b in (("WT", "dWT"), ("bE", "dbE"), ("WsT", "dWsT"), ("bs", "dbs")):
-                out[f"c{l}.{a}"] = [gk[f"c{l}.{b}"]]
+        for l, conv in enumerate(self.rgcn_convs):
+            if self._fused(l):
+                d = conv.in_channels
+                o1, cs = gk[f"c{l}.o1"], gk[f"c{l}.cs"]
+                out[f"c{l}.WT"] = [o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)]
+                out[f"c{l}.WsT"] = [o1[:, 4 * d:]]
+                out[f"c{l}.bE"] = [gk[f"c{l}.dbE"]]
+                out[f"c{l}.bs"] = [cs[4 * d:]]
+            else:
+                for a, b in (("WT", "dWT"), ("bE", "dbE"), ("WsT", "dWsT"), ("bs", "dbs")):
+                    out[f"c{l}.{a}"] = [gk[f"c{l}.{b}"]]
         return out
 
     def _forward_fast(self, pb, fast):
@@ -166,6 +189,11 @@ class RelGCN(nn.Module):
         x = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
         pbs = rescale_adj(pb) if self.scale_adj else pb
         for l in range(len(self.rgcn_convs)):
+            if self._fused(l):
+                W = {k: P[f"c{l}.{k}"] for k in ("WTp", "bE", "WsTp", "bs", "Wnat_p", "Ws_p")}
+                Gl = {k: G[f"c{l}.{k}"] for k in ("o1", "dbE", "cs")}
+                x = Fn.PRelLayerFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
+                continue
             W = {k: P[f"c{l}.{k}"] for k in ("WT", "bE", "WsT", "bs", "Wnat", "Ws")}
             Gl = {k: G[f"c{l}.{k}"] for k in ("dWT", "dbE", "dWsT", "dbs")}
             x = Fn.PMsgFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])

@@ -543,6 +543,199 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #undef RM_C4
 #undef RM_LDS
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused RelGCN layer (models/update/relgcn_update.py:24-44 + the tanh of models/relgcn.py:71):
+//   out = act(h W_s^T + b_s + sum_e adj'_e (W_e h + b_e))
+// = the message half of the GGNN step plus one more K = D pass over the resident h tile (the self connection) and the
+// activation in the epilogue.  d_in == d_out == D.  The 1/degree of rescale_adj is in the CSR values.
+// ---------------------------------------------------------------------------------------------
+struct RelArgs {
+    const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
+    int act;
+    // forward
+    const float* h;                 // [N x D]
+    const float* WT;                // [4D x D]  K4-packed, rows e*D + k
+    const float* bE;                // [4 x D]
+    const float* WsT;               // [D x D]   K4-packed
+    const float* bs;                // [D]
+    float* out;                     // [N x D]
+    float* wdeg;                    // [N x 4]   weighted degree per bond type (the backward's db_e operand)
+    // backward
+    const float* dout; const float* y;
+    const float* Wnat;              // [D x 4D]  (= WT^T) K4-packed
+    const float* Ws;                // [D x D]   (= WsT^T) K4-packed
+    float* dh;
+    float* gda;                     // [N x 5D]: G_0..G_3 (transposed gather of dpre per bond type) | dpre
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
+    constexpr int LD = D + 4;
+    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Hs = lds;
+    float* As = lds + FZ_R * LD;
+    float* wds = As + FZ_R * LD;
+    int* rptr = (int*)(wds + FZ_R * 4);
+    int* ecol = rptr + 132;
+    float* evalv = (float*)(ecol + FZ_ECAP);
+    int* sy = (int*)(evalv + FZ_ECAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int grp = w >> 2;
+    GrpSync gs{sy + grp, 0};
+    int tmask = 0;
+    if (tid < FZ_NSYNC) sy[tid] = 0;
+    if (grp == 0) __builtin_amdgcn_s_setprio(2);
+    const int wc = w % NCB, wr = w / NCB;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * FZ_R;
+    const int col = wc * 32 + l31;
+    const int wrow0 = wr * RB * 32;
+    const int lrow = wrow0 + 4 * hi;
+    const int rot = (blockIdx.x * 8) % D;
+    const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
+    const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
+
+    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+        const int r = idx / (D / 4), c4 = idx % (D / 4);
+        *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
+    }
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);
+    __syncthreads();
+
+    f32x16 acc[1][RB];
+    zero_acc(acc[0]);
+    const float* const Bs[1] = {a.WsT + (size_t)(4 * hi) * D + 4 * col};
+    const int lds_[1] = {D};
+    BPre<1> pre_s;
+    for (int e = 0; e < 4; ++e) {
+        const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
+        const int ldw[1] = {D};
+        BPre<1> pre;
+        tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
+        if (e == 3) tile_b_prefetch<1>(pre_s, Bs, lds_, D, rot);
+        float wd;
+        FZ_GATHER(Hs, As, e, &wd);
+        if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
+        if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        grp_sync(gs);
+        const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
+        if (any) tile_mma<1, RB>(acc, Aw, LD, Bp, ldw, D, rot, &pre);
+        FZ_GSYNC();
+    }
+    tile_mma<1, RB>(acc, Hw, LD, Bs, lds_, D, rot, &pre_s);          // self connection: h . W_s^T
+    {
+        const AccBuf oo = acc_buf<D>(a.out, row0, lrow, col);
+        float be[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) be[e] = a.bE[e * D + col];
+        const float bsv = a.bs ? a.bs[col] : 0.f;
+        const int act = a.act;
+        FZ_FOR_ACC {
+            const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+            const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
+            const float v = acc[0][rb][reg] + bsv + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
+            acc_st<D>(oo, rb, reg, bmp_act(act, v));
+        }
+    }
+    if ((tid & 255) < 64) {           // this half's weighted degrees (written by this half's threads, group-synced above)
+        const int r = grp * 64 + (tid & 255);
+        *(f32x4*)(a.wdeg + (size_t)(row0 + r) * 4) = *(const f32x4*)(wds + r * 4);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
+    constexpr int LD = D + 4;
+    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    constexpr int F4 = D / 4;
+    constexpr int NV = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;                         // [128 x LD]  dpre (read-only after the prologue)
+    float* Ys = lds + FZ_R * LD;             // [128 x LD]  G_e -> dh
+    int* rptr = (int*)(Ys + FZ_R * LD + FZ_R * 4);
+    int* ecol = rptr + 132;
+    float* evalv = (float*)(ecol + FZ_ECAP);
+    int* sy = (int*)(evalv + FZ_ECAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int grp = w >> 2;
+    GrpSync gs{sy + grp, 0};
+    int tmask = 0;
+    if (tid < FZ_NSYNC) sy[tid] = 0;
+    if (grp == 0) __builtin_amdgcn_s_setprio(2);
+    const int wc = w % NCB, wr = w / NCB;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * FZ_R;
+    const int col = wc * 32 + l31;
+    const int wrow0 = wr * RB * 32;
+    const int lrow = wrow0 + 4 * hi;
+    const int rot = (blockIdx.x * 8) % D;
+    const float* Xw = Xs + (wrow0 + l31) * LD + 4 * hi;
+    const float* Yw = Ys + (wrow0 + l31) * LD + 4 * hi;
+    float* Yl = Ys + lrow * LD + col;
+    const int tg = tid & 255;
+#define RM_ROW(v) (grp * 64 + ((v) * 256 + tg) / F4)
+#define RM_C4(v) (((v) * 256 + tg) % F4)
+#define RM_LDS(T, v) (*(f32x4*)((T) + RM_ROW(v) * LD + 4 * RM_C4(v)))
+    const AccBuf b_g = rm_buf<D, D>(a.dout, row0, grp, tg), b_y = rm_buf<D, D>(a.y, row0, grp, tg);
+    const AccBuf b_o = rm_buf<D, 5 * D>(a.gda, row0, grp, tg), b_dh = rm_buf<D, D>(a.dh, row0, grp, tg);
+
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);
+
+    {   // dpre = dout * act'(out) -> X and gda[:, 4D:]
+        f32x4 g4[NV], y4[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { g4[v] = rm_ld<D, D>(b_g, v); y4[v] = rm_ld<D, D>(b_y, v); }
+        const int act = a.act;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            f32x4 dp;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dp[t] = g4[v][t] * bmp_dact(act, y4[v][t]);
+            RM_LDS(Xs, v) = dp;
+            rm_st<D, 5 * D>(b_o, v, dp, 4 * D);
+        }
+    }
+    const float* const Bs[1] = {a.Ws + (size_t)(4 * hi) * D + 4 * col};
+    const int lds_[1] = {D};
+    BPre<1> pre_s;
+    tile_b_prefetch<1>(pre_s, Bs, lds_, D, rot);
+    __syncthreads();
+
+    f32x16 acc_h[1][RB];
+    zero_acc(acc_h[0]);
+    tile_mma<1, RB>(acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s);        // dh = dpre . W_s
+    for (int e = 0; e < 4; ++e) {
+        const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
+        const int ldw[1] = {4 * D};
+        BPre<1> pre;
+        tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
+        float wd;
+        FZ_GATHER(Xs, Ys, e, &wd);
+        {
+            const int row = tid >> 2, q = tid & 3;
+            const float* s = Ys + row * LD + q * (D / 4);
+            float* o = a.gda + (size_t)(row0 + row) * 5 * D + e * D + q * (D / 4);
+#pragma unroll
+            for (int f = 0; f < D / 16; ++f) *(f32x4*)(o + 4 * f) = *(const f32x4*)(s + 4 * f);
+        }
+        if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        grp_sync(gs);
+        const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
+        if (any) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
+        FZ_GSYNC();
+    }
+    FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
+    FZ_GSYNC();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v));
+#undef RM_ROW
+#undef RM_C4
+#undef RM_LDS
+}
 #undef LOFF
 
 // ---------------------------------------------------------------------------------------------
@@ -627,4 +820,66 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
         if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+// ---- fused RelGCN layer (d_in == d_out in {64, 128}) ----
+extern "C" int bmp_relgcn_layer_supported(int d_in, int d_out) { return d_in == d_out && bmp_ggnn_step_supported(d_in); }
+
+template <int D>
+static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
+    const void* fn = bwd ? (const void*)k_relgcn_layer_bwd<D> : (const void*)k_relgcn_layer_fwd<D>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[bwd ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
+        if (e != hipSuccess) return (int)e;
+        attr_set[bwd ? 1 : 0] = true;
+    }
+    const double rows = (double)n_tiles * FZ_R;
+    BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * 5.0 * D * D, 4.0 * rows * D * (bwd ? 8.0 : 2.0), st);
+    if (bwd) hipLaunchKernelGGL((k_relgcn_layer_bwd<D>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_relgcn_layer_fwd<D>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// out = act(h . WsT + bs + sum_e gather_e(h) . WT_e + wdeg_e * bE_e); WT [4d x d] and WsT [d x d] K4-packed
+// (bmp/functional.py:pack_k4).  Saves wdeg [N x 4].
+extern "C" int bmp_relgcn_layer_fwd(const float* h, int n_tiles, int d, const int* csr_ptr, const int* csr_col,
+                                    const float* csr_val, const float* WT, const float* bE, const float* WsT, const float* bs,
+                                    int act, float* out, float* wdeg, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+    RelArgs a; memset(&a, 0, sizeof(a));
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act;
+    a.h = h; a.WT = WT; a.bE = bE; a.WsT = WsT; a.bs = bs; a.out = out; a.wdeg = wdeg;
+    return d == 128 ? rel_launch<128>(false, a, n_tiles, st) : rel_launch<64>(false, a, n_tiles, st);
+}
+
+// dh and gda [N x 5d] = [G_0..G_3 | dpre] for bmp_relgcn_layer_wgrad.  Wnat [d x 4d] = WT^T, Ws [d x d] = WsT^T, K4-packed.
+extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
+                                    const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
+                                    float* gda, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+    RelArgs a; memset(&a, 0, sizeof(a));
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act;
+    a.dout = dout; a.y = out; a.Wnat = Wnat; a.Ws = Ws; a.dh = dh; a.gda = gda;
+    return d == 128 ? rel_launch<128>(true, a, n_tiles, st) : rel_launch<64>(true, a, n_tiles, st);
+}
+
+extern "C" size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d) {
+    size_t a = bmp_wgrad_ws_floats(N, d, 5 * d), b = bmp_wgrad_ws_floats(N, 4, d);
+    return a > b ? a : b;
+}
+
+// Weight gradients of one layer (reduction over all N rows):
+//   o1 [d x 5d] = h^T . gda     cols [0,4d): dWT as [k][e*d + c];  cols [4d,5d): dWsT
+//   dbE [4 x d] = wdeg^T . dpre
+//   cs [5d]     = column sums of gda; cs[4d:] = dbs
+extern "C" int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
+                                      float* cs, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
+    BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_relgcn_layer_wgrad_ws_floats(N, d));
+    int rc;
+    WGArgs g1{h, nullptr, d, 0, gda, 5 * d, d, 5 * d, N, o1, 5 * d, accumulate, cs};
+    if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
+    WGArgs g2{wdeg, nullptr, 4, 0, gda + 4 * d, 5 * d, 4, d, N, dbE, d, accumulate};
+    return bmp_launch_wgrad(g2, ws, st);
 }

@@ -95,6 +95,25 @@ int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const f
                         float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats,
                         bmp_stream_t stream);
 
+/* One whole RelGCN layer, fused per 128-row tile -- RelGCNUpdate.__call__ models/update/relgcn_update.py:24-44 with
+ * the tanh of models/relgcn.py:71: out = act(h W_s^T + b_s + sum_e adj'_e (W_e h + b_e)), the 1/degree of rescale_adj
+ * (models/relgcn.py:20-28) carried by the CSR values.  d_in == d_out == d with bmp_relgcn_layer_supported (64 or 128);
+ * other shapes use bmp_msg_fwd/bwd.  WT [4d x d], WsT [d x d] (fwd) and Wnat [d x 4d] = WT^T, Ws [d x d] = WsT^T (bwd)
+ * are K4-packed as for bmp_ggnn_step_*.  fwd saves wdeg [N x 4] (weighted degree per bond type).
+ * bwd writes dh [N x d] and gda [N x 5d] = [G_0..G_3 (transposed-gathered dpre per bond type) | dpre].
+ * wgrad: o1 [d x 5d] = h^T.gda (cols [0,4d): dWT as [k][e*d+c]; cols [4d,5d): dWsT), dbE [4 x d] = wdeg^T.dpre,
+ * cs [5d] = column sums of gda (cs[4d:] = dbs). */
+int bmp_relgcn_layer_supported(int d_in, int d_out);
+int bmp_relgcn_layer_fwd(const float* h, int n_tiles, int d, const int* csr_ptr, const int* csr_col, const float* csr_val,
+                         const float* WT, const float* bE, const float* WsT, const float* bs, int act, float* out,
+                         float* wdeg, bmp_stream_t stream);
+int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
+                         const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
+                         float* gda, bmp_stream_t stream);
+size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d);
+int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
+                           float* cs, int accumulate, float* ws, size_t ws_floats, bmp_stream_t stream);
+
 /* Gated-sum readout -- GGNN.readout models/ggnn.py:333-341 and GGNNReadout.__call__
  * models/readout/ggnn_readout.py:42-57.  g[mol] = sum_rows w * sigmoid(i(.)) * act_j(j(.)).
  * WT [(d+d0) x 2o] cols [i|j]; h0 may be NULL (d0 ignored).  Saves ij [N x 2o]. */

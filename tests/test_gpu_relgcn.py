@@ -22,7 +22,9 @@ def pairs():
     return store, i1, i2, packed.pack_from_store(ms, [i1, i2], device="cpu", with_dense_map=True)
 
 
-@pytest.mark.parametrize("ch_list,out,scale", [([16, 128, 64], 64, True), ([8, 8, 8, 8], 8, True), ([16, 24], 12, False)])
+@pytest.mark.parametrize("ch_list,out,scale", [([16, 128, 64], 64, True), ([8, 8, 8, 8], 8, True), ([16, 24], 12, False),
+                                               ([64, 64, 64], 32, True), ([128, 128, 128, 128], 128, True),    # fused layers
+                                               ([16, 64, 64, 32], 16, False)])                                   # mixed
 def test_relgcn_matches_dense_oracle(pairs, ch_list, out, scale):
     from bmp.relgcn import RelGCN
     from bmp.snapshot import load_param_dict, grad_dict
@@ -34,7 +36,8 @@ def test_relgcn_matches_dense_oracle(pairs, ch_list, out, scale):
     g1, at1 = O.relgcn_forward(p, T(a1), T(j1).double(), len(ch_list) - 1, scale)
     g2, at2 = O.relgcn_forward(p, T(a2), T(j2).double(), len(ch_list) - 1, scale)
     g_ref = torch.cat((g1, g2))
-    cg = torch.randn(g_ref.shape, dtype=torch.float64); ca = torch.randn(at1.shape, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(5)
+    cg = torch.randn(g_ref.shape, dtype=torch.float64, generator=gen); ca = torch.randn(at1.shape, dtype=torch.float64, generator=gen)
     ((g_ref * cg).sum() + 0.1 * (at1 * ca).sum()).backward()
     enc = RelGCN(out_channels=out, ch_list=ch_list, scale_adj=scale).to(dev())
     load_param_dict(enc, p)
@@ -116,3 +119,32 @@ def test_pair_relgcn_golden(golden_dir):
     loss.backward()
     for name, gr in grad_dict(model).items():
         close(gr, T(z["grad:" + name]), f"grad {name}")
+
+
+@pytest.mark.parametrize("d,act", [(64, "tanh"), (128, "tanh"), (128, "identity")])
+def test_fused_relgcn_layer_equals_the_unfused_path(pairs, d, act):
+    """bmp_relgcn_layer_* (one kernel per tile) against bmp_msg_* (gather + row GEMMs) on the same inputs: outputs,
+    input gradient and all four parameter gradients."""
+    from bmp import functional as Fn
+    from bmp.relgcn import rescale_adj
+    store, i1, i2, pb = pairs
+    pbd = rescale_adj(to_dev(pb))
+    g = torch.Generator().manual_seed(d)
+    mk = lambda *s_: (torch.randn(*s_, generator=g) * 0.2).to(dev())
+    x0 = mk(pb.n_rows, d) * 3
+    WT0, bE0, WsT0, bs0 = mk(4 * d, d), mk(4, d), mk(d, d), mk(d)
+    cw = mk(pb.n_rows, d)
+    res = []
+    for fn in (Fn.RelLayerFn, Fn.MsgFn):
+        x, WT, bE, WsT, bs = (t.clone().requires_grad_() for t in (x0, WT0, bE0, WsT0, bs0))
+        y = fn.apply(x, WT, bE, WsT, bs, pbd, Fn.ACT[act])
+        (y * cw).sum().backward()
+        res.append((y, x.grad, WT.grad, bE.grad, WsT.grad, bs.grad))
+    rows = torch.zeros(pb.n_rows, dtype=torch.bool)
+    for r0, nr in zip(pb.mol_row0.tolist(), pb.mol_nrows.tolist()):
+        rows[r0:r0 + nr] = True                                  # rows of no molecule carry unspecified values
+    rows = rows.to(dev())
+    for name, a, b in zip(("out", "dx", "dWT", "dbE", "dWsT", "dbs"), res[0], res[1]):
+        if name in ("out", "dx"):
+            a, b = a[rows], b[rows]
+        close(a, b, name)

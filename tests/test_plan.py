@@ -30,11 +30,12 @@ def test_plan_tables_match_layout_code(tying, n_layers):
     pool = PoolingFineCoattention(hidden_dim=8, out_dim=12)
     from bmp.relgcn import RelGCN
     rel = RelGCN(out_channels=12, ch_list=[8, 16, 8])
+    rel2 = RelGCN(out_channels=12, ch_list=[64, 64])             # its layer takes the fused kernel's layouts
     with torch.no_grad():
-        for m in (enc, att, pool, rel):
+        for m in (enc, att, pool, rel, rel2):
             for p in m.parameters():
                 p.copy_(torch.randn_like(p))
-    mods = [("graph_conv.", enc), ("attn.", att), ("pool.", pool), ("rel.", rel)]
+    mods = [("graph_conv.", enc), ("attn.", att), ("pool.", pool), ("rel.", rel), ("rel2.", rel2)]
     names, shapes, flat = _flat_of(mods)
     plan = LayoutPlan(mods, names, shapes, "cpu")
     # (i) prepare == the layout functions, bit for bit
