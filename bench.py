@@ -114,6 +114,11 @@ def main():
     dev_index = 0 if one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    force_pg = world == 1 and os.environ.get("BMP_BENCH_FORCE_PG") == "1"      # rehearsal: the RCCL call path on one rank
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -151,6 +156,8 @@ def main():
     model = build_pair_predictor(hidden_dim=D, out_dim=O, n_layers=T_STEPS, attn="nie", head=HEAD).to(dev)
     opt = FlatAdam(model, alpha=1e-3)
     opt.broadcast_parameters(0)
+    if force_pg:
+        opt.world = 2            # takes the all-reduce branch (a one-rank sum; the folded 1/2 only rescales the updates)
 
     def step(i, collective=True):
         pb, t = batches[i % N_DISTINCT_BATCHES]
@@ -248,7 +255,7 @@ def main():
                        "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": gb, "parallelism": f"dp{world}",
                        "atoms_per_pair": round(atoms_per_pair, 2), "loss": round(float(loss.item()), 5)},
             "roofline": roof, "whole_step": whole, "cpu_baseline": cpu}))
-    if world > 1:
+    if world > 1 or force_pg:
         dist.barrier()
         dist.destroy_process_group()
 
