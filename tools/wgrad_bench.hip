@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <math.h>
+#include <algorithm>
 #include "bmp_common.h"
 
 #define WG_LD 132
@@ -218,6 +220,83 @@ __global__ __launch_bounds__(512) void k_wg_wide(WGKArgs a) {
         }
 }
 
+
+// variant: 128 x 256 output tile, 512 threads, THREE LDS stages filled by LDS-DMA (global_load_lds_dwordx4) two stages
+// ahead; counted vmcnt + raw s_barrier, one barrier per 32-row stage, one workgroup per CU (144 KB of LDS)
+#define DW_NS 3
+__global__ __launch_bounds__(512) void k_wg_dmaw(WGKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int XSZ = 32 * 128, YSZ = 32 * 256, SSZ = XSZ + YSZ;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int j_tile = blockIdx.y * 256;
+    const int s = blockIdx.z;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) >> 5;
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    // per-lane source addresses of this wave's six pieces of a stage (row offsets relative to the stage's first row)
+    int ycol = j_tile + 4 * lane;
+    if (ycol > a.Nn - 4) ycol = a.Nn - 4;                  // columns past the matrix: any valid address, results are masked
+    const float* xsrc = a.X + (size_t)(r_begin + 2 * w + (lane >> 5)) * a.ldx + 4 * (lane & 31);
+    const float* ysrc = a.dY + (size_t)(r_begin + w) * a.ldy + ycol;
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef const __attribute__((address_space(1))) float glb_f;
+#define DW_ISSUE(st)                                                                                         \
+    {                                                                                                        \
+        float* base = sm + ((st) % DW_NS) * SSZ;                                                             \
+        const size_t ro = (size_t)(st) * 32;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+            __builtin_amdgcn_global_load_lds((glb_f*)(xsrc + (ro + 16 * i) * a.ldx), (lds_f*)(base + (2 * w + 16 * i) * 128), 16, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+            __builtin_amdgcn_global_load_lds((glb_f*)(ysrc + (ro + 8 * i) * a.ldy), (lds_f*)(base + XSZ + (w + 8 * i) * 256), 16, 0, 0); \
+    }
+    if (nst > 0) DW_ISSUE(0)
+    if (nst > 1) DW_ISSUE(1)
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < nst) DW_ISSUE(st + 2)
+        const float* XS = sm + (st % DW_NS) * SSZ;
+        const float* YS = XS + XSZ;
+        float av[2][2][4], bv[2][2][4];
+#define DFRAG(slot, k0)                                                                            \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) av[slot][m][t] = XS[((k0) + 4 * hi + t) * 128 + wm * 64 + m * 32 + l31]; \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) bv[slot][n][t] = YS[((k0) + 4 * hi + t) * 256 + wn * 64 + n * 32 + l31]; \
+    }
+        DFRAG(0, 0)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 4) { DFRAG(cur ^ 1, (ks + 1) * 8) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t], bv[cur][n][t], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* slab = a.slab + (size_t)s * a.K * a.Nn;
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+            if (j < a.Nn)
+                for (int reg = 0; reg < 16; ++reg) slab[(size_t)(wm * 64 + m * 32 + bmp_acc_row(reg, lane)) * a.Nn + j] = acc[m][n][reg];
+        }
+}
+static void launch_dmaw(const WGKArgs& a, int tiles, int S) {
+    const size_t lds = (size_t)DW_NS * (32 * 128 + 32 * 256) * 4;
+    hipFuncSetAttribute((const void*)k_wg_dmaw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_wg_dmaw, dim3(1, (a.Nn + 255) / 256, S), dim3(512), lds, 0, a);
+}
+
 static float run_k(void (*launch)(const WGKArgs&, int, int), const WGKArgs& a, int tiles, int S, int reps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -281,6 +360,18 @@ int main(int argc, char** argv) {
             int Sw = 256 / wt; int rw = ((N + Sw - 1) / Sw + 31) & ~31; Sw = (N + rw - 1) / rw;
             WGKArgs b = a; b.rows_per_split = rw;
             if ((size_t)Sw <= (size_t)S) printf("  wide 128x256 (S %d) %7.1f us\n", Sw, run_k(launch_wide, b, wt, Sw, 20));
+            if ((size_t)Sw <= (size_t)S) {
+                printf("  wide DMA ring (S %d) %7.1f us\n", Sw, run_k(launch_dmaw, b, wt, Sw, 20));
+                // check against the plain kernel on a few slab sums
+                std::vector<float> r0((size_t)K * Nn), r1((size_t)K * Nn, 0.f), tmp((size_t)K * Nn);
+                hipLaunchKernelGGL((k_wg<0>), dim3(1, tiles, S), dim3(256), 0, 0, a); hipDeviceSynchronize();
+                std::fill(r0.begin(), r0.end(), 0.f);
+                for (int q = 0; q < S; ++q) { hipMemcpy(tmp.data(), slab + (size_t)q * K * Nn, tmp.size() * 4, hipMemcpyDeviceToHost); for (size_t e = 0; e < tmp.size(); ++e) r0[e] += tmp[e]; }
+                launch_dmaw(b, wt, Sw); hipDeviceSynchronize();
+                for (int q = 0; q < Sw; ++q) { hipMemcpy(tmp.data(), slab + (size_t)q * K * Nn, tmp.size() * 4, hipMemcpyDeviceToHost); for (size_t e = 0; e < tmp.size(); ++e) r1[e] += tmp[e]; }
+                double md = 0, mx = 0; for (size_t e = 0; e < r0.size(); ++e) { md = fmax(md, fabs((double)r0[e] - r1[e])); mx = fmax(mx, fabs((double)r0[e])); }
+                printf("  wide DMA ring vs plain: max diff %.3e (scale %.3e)\n", md, mx);
+            }
         }
         hipFree(slab);
     }
