@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void k_wg(WGKArgs a) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
             const size_t row = (size_t)(r_begin + (st) * 32 + rr + 8 * i);                       \
             xr[i] = *(const f32x4*)(a.X + row * a.ldx + colx);                                   \
-            yr[i] = *(const f32x4*)(a.dY + row * a.ldy + coly);                                  \
+            yr[i] = (MODE & 8) ? *(const f32x4*)(a.dY + (size_t)blockIdx.y * a.N * 128 + row * 128 + 4 * c4)   \
+                               : *(const f32x4*)(a.dY + row * a.ldy + coly);                     \
         }                                                                                        \
     }
 #define WG_STORE(buf)                                                                            \
@@ -349,6 +350,8 @@ int main(int argc, char** argv) {
         const double gf = 2.0 * N * K * (double)Nn / 1e9;
         printf("N %d Nn %d tiles %d S %d rows/split %d  (%.1f GFLOP, ideal %.1f us at 157.3 TF)\n", N, Nn, tiles, S, rps, gf, gf / 157.3e3 * 1e6);
         printf("  full            %7.1f us\n", run<0>(a, tiles, S, 20));
+        printf("  full, dY column-group-major %7.1f us\n", run<8>(a, tiles, S, 20));
+        printf("  loads only, group-major     %7.1f us\n", run<13>(a, tiles, S, 20));
         printf("  no MFMA         %7.1f us\n", run<1>(a, tiles, S, 20));
         printf("  no global loads %7.1f us\n", run<2>(a, tiles, S, 20));
         printf("  no LDS          %7.1f us\n", run<4>(a, tiles, S, 20));
