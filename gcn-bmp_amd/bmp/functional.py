@@ -246,6 +246,25 @@ class GGNNStepFn(Function):
         return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None, None
 
 
+def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o):
+    """The readout forward: one kernel per tile when the shape allows (WTp = pack_k4(WT), made here if not given),
+    else row GEMM + segment sum.  Returns (ij, g)."""
+    L = _lib.lib()
+    N, d = h.shape
+    d0 = 0 if h0 is None else h0.shape[1]
+    ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+    g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
+    if pb.row_mol is not None and L.bmp_readout_tile_supported(d, d0, o):
+        if WTp is None:
+            WTp = pack_k4(WT)
+        check(L.bmp_readout_tile_fwd(ptr(h), ptr(h0), pb.n_tiles, d, ptr(WTp), ptr(b), act_j, ptr(pb.row_w), ptr(pb.row_mol),
+                                     ptr(pb.mol_nrows), ptr(ij), ptr(g), stream()), "bmp_readout_tile_fwd")
+    else:
+        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(b), act_j, ptr(pb.row_w),
+                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()), "bmp_readout_fwd")
+    return ij, g
+
+
 class ReadoutFn(Function):
     """Gated-sum readout (models/ggnn.py:333-341; models/readout/ggnn_readout.py:42-57).
     WT [(d+d0) x 2o] cols [i|j]; b [2o] or None; h0 may be None."""
@@ -264,11 +283,7 @@ class ReadoutFn(Function):
             raise ValueError("readout: weight shape does not match [h, h0]")
         WT = WT.contiguous()
         b = None if b is None else b.contiguous()
-        ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
-        g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
-        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(b), act_j, ptr(pb.row_w),
-                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()),
-              "bmp_readout_fwd")
+        ij, g = _readout_fwd(h, h0, pb, WT, None, b, act_j, o)
         ctx.save_for_backward(h, h0 if h0 is not None else torch.empty(0), WT, ij)
         ctx.pb, ctx.act_j, ctx.has_h0, ctx.has_b, ctx.o = pb, act_j, h0 is not None, b is not None, o
         return g
@@ -444,11 +459,7 @@ class PReadoutFn(Function):
         ctx.state = state
         WT = W["WT"]
         o = WT.shape[1] // 2
-        ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
-        g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
-        check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(W.get("b")), act_j, ptr(pb.row_w),
-                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()),
-              "bmp_readout_fwd")
+        ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o)
         ctx.save_for_backward(h, ij, *([h0] if h0 is not None else []))
         ctx.pb, ctx.W, ctx.G, ctx.act_j, ctx.o = pb, W, G, act_j, o
         return g

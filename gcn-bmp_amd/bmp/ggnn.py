@@ -184,6 +184,8 @@ class GGNN(nn.Module):
         p = self.primary_layouts()
         out = {"embed.W": p["embed.W"], "gru.UcTp": Fn.pack_k4(p["gru.UcT"]), "gru.Uc_p": Fn.pack_k4(p["gru.UcT"].t()),
                "ro.WT": p["ro.WT"], "ro.b": p["ro.b"], "ro.Wnat": p["ro.WT"].t().contiguous()}
+        if p["ro.WT"].shape[0] % 4 == 0:
+            out["ro.WTp"] = Fn.pack_k4(p["ro.WT"])             # the tile-kernel form of the readout forward
         for li in range(self.n_message_layer):
             WT = p[f"msg{li}.WT"]
             out[f"msg{li}.WTp"], out[f"msg{li}.bE"], out[f"msg{li}.Wnat_p"] = Fn.pack_k4(WT), p[f"msg{li}.bE"], Fn.pack_k4(WT.t())
@@ -230,7 +232,7 @@ class GGNN(nn.Module):
             Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
             h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0)
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
-        return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
+        return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
                                    dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state)
 
     def forward(self, atom_array, adj=None):

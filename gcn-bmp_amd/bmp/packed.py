@@ -126,6 +126,7 @@ class PackedMolBatch:
     n_edges: int = 0
     max_rows_per_mol: int = 0
     mol_nrows_host: Optional[np.ndarray] = None   # host copy of mol_nrows (pair metadata without a device sync)
+    row_mol: Optional[torch.Tensor] = None        # (N,) molecule of every row, -1 for rows of no molecule
     _cache: dict = field(default_factory=dict, repr=False)
 
     @property
@@ -187,7 +188,9 @@ def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
     csr_ptr, csr_col, csr_val = build(dst, src)
     csrT_ptr, csrT_col, csrT_val = build(src, dst)
 
-    ints = [atom_id, csr_ptr, csr_col, csrT_ptr, csrT_col, inst_row0.astype(np.int32), inst_nrows.astype(np.int32)]
+    row_mol = np.full(N, -1, dtype=np.int32)
+    row_mol[rowmap] = np.repeat(np.arange(I, dtype=np.int32), inst_nrows)
+    ints = [atom_id, csr_ptr, csr_col, csrT_ptr, csrT_col, inst_row0.astype(np.int32), inst_nrows.astype(np.int32), row_mol]
     flts = [row_w, csr_val, csrT_val]
     ibuf = torch.from_numpy(np.concatenate(ints)).to(device)
     fbuf = torch.from_numpy(np.concatenate(flts)).to(device)
@@ -211,7 +214,7 @@ def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
         dense_maps=dmaps,
         n_real_atoms=int((flat_w == 1).sum()), n_edges=int(len(e_dst)),
         max_rows_per_mol=int(inst_nrows.max()) if I else 0,
-        mol_nrows_host=inst_nrows.astype(np.int64),
+        mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[7],
     )
 
 
@@ -384,8 +387,10 @@ def pack_from_dense_device(atom_arrays: Sequence, adjs: Sequence[torch.Tensor], 
     csr_ptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg_in, out=csr_ptr[1:])
     csrT_ptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg_out, out=csrT_ptr[1:])
     E = int(csr_ptr[-1])
+    row_mol = np.full(N, -1, dtype=np.int32)
+    row_mol[rowmap] = np.repeat(np.arange(I, dtype=np.int32), inst_nrows)
     ints = [atom_id, csr_ptr.astype(np.int32), csrT_ptr.astype(np.int32), inst_row0.astype(np.int32),
-            inst_nrows.astype(np.int32)] + [dr.astype(np.int32).ravel() for dr in dense_rows]
+            inst_nrows.astype(np.int32)] + [dr.astype(np.int32).ravel() for dr in dense_rows] + [row_mol]
     ibuf = torch.from_numpy(np.concatenate(ints)).to(dev)
     iv, o = [], 0
     for a in ints:
@@ -404,4 +409,4 @@ def pack_from_dense_device(atom_arrays: Sequence, adjs: Sequence[torch.Tensor], 
         mol_row0=iv[3], mol_nrows=iv[4], side_tiles=tuple(side_tiles), side_mols=tuple(side_mols),
         dense_map=dmaps[0] if len(dmaps) == 1 else None, dense_maps=dmaps,
         n_real_atoms=int((flat_w == 1).sum()), n_edges=E, max_rows_per_mol=int(inst_nrows.max()) if I else 0,
-        mol_nrows_host=inst_nrows.astype(np.int64))
+        mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[-1])

@@ -156,6 +156,8 @@ class RelGCN(nn.Module):
                 out[f"c{l}.Wnat"] = p[f"c{l}.WT"].t().contiguous()
                 out[f"c{l}.Ws"] = p[f"c{l}.WsT"].t().contiguous()
         out["ro.Wnat"] = p["ro.WT"].t().contiguous()
+        if p["ro.WT"].shape[0] % 4 == 0:
+            out["ro.WTp"] = Fn.pack_k4(p["ro.WT"])
         return out
 
     def gk_spec(self):
@@ -198,7 +200,7 @@ class RelGCN(nn.Module):
             Gl = {k: G[f"c{l}.{k}"] for k in ("dWT", "dbE", "dWsT", "dbs")}
             x = Fn.PMsgFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
         self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
-        return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"]), dict(dWT=G["ro.dWT"]),
+        return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")), dict(dWT=G["ro.dWT"]),
                                    Fn.ACT["tanh"], state)
 
     def forward(self, h, adj=None):

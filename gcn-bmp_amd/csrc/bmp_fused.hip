@@ -736,6 +736,107 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
 #undef RM_C4
 #undef RM_LDS
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gated-sum readout forward on the tile machinery (models/ggnn.py:333-341, models/readout/ggnn_readout.py:42-57) for
+// d == o in {64, 128}, h0 absent or d wide:  [i | j] = [h, h0] . WT + b ; g[mol] = sum_rows w * sigmoid(i) * act_j(j).
+// The tile's rows are resident in LDS, the 2o output columns are two accumulators per wave (same column of i and j, so
+// the gate is formed in registers), and because a molecule never leaves its tile the per-molecule sums are taken
+// from LDS in a fixed order by the tile's own workgroup: no second kernel, no re-read of ij.
+// ---------------------------------------------------------------------------------------------
+struct ROArgs {
+    const float* h; const float* h0;
+    const float* WT;                // [(D + D0) x 2D] K4-packed, columns [i | j]
+    const float* b;                 // [2D] or nullptr
+    int act_j;
+    const float* row_w; const int* row_mol; const int* mol_nrows;
+    float* ij;                      // [N x 2D]  sigmoid(i) | act_j(j)   (the backward's input)
+    float* g;                       // [n_mols x D]
+};
+
+template <int D, bool HAS0>
+__global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
+    constexpr int LD = D + 4;
+    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Hs = lds;                         // [128 x LD]  h tile
+    float* As = lds + FZ_R * LD;             // [128 x LD]  h0 tile -> w * sigmoid(i) * act_j(j)
+    int* mlist = (int*)(As + FZ_R * LD);     // [64 x 2] (first tile row, molecule) + [2] counts
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wc = w % NCB, wr = w / NCB;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = blockIdx.x * FZ_R;
+    const int col = wc * 32 + l31;
+    const int wrow0 = wr * RB * 32;
+    const int lrow = wrow0 + 4 * hi;
+    const int rot = (blockIdx.x * 8) % D;
+    const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
+    const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
+    float* Al = As + lrow * LD + col;
+
+    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+        const int r = idx / (D / 4), c4 = idx % (D / 4);
+        *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
+        if (HAS0) *(f32x4*)(As + r * LD + 4 * c4) = *(const f32x4*)(a.h0 + (size_t)(row0 + r) * D + 4 * c4);
+    }
+    const float* const Bh[2] = {a.WT + (size_t)(4 * hi) * 2 * D + 4 * col, a.WT + (size_t)(4 * hi) * 2 * D + 4 * (D + col)};
+    const int ldw[2] = {2 * D, 2 * D};
+    BPre<2> pre_h;
+    tile_b_prefetch<2>(pre_h, Bh, ldw, D, rot);
+    __syncthreads();
+
+    f32x16 acc[2][RB];                       // [0] = i, [1] = j
+    zero_acc(acc[0]); zero_acc(acc[1]);
+    if (HAS0) {
+        const float* const B0[2] = {Bh[0] + (size_t)D * 2 * D, Bh[1] + (size_t)D * 2 * D};
+        BPre<2> pre_0;
+        tile_b_prefetch<2>(pre_0, B0, ldw, D, rot);
+        tile_mma<2, RB>(acc, Hw, LD, Bh, ldw, D, rot, &pre_h);
+        tile_mma<2, RB>(acc, Aw, LD, B0, ldw, D, rot, &pre_0);
+    } else {
+        tile_mma<2, RB>(acc, Hw, LD, Bh, ldw, D, rot, &pre_h);
+    }
+    // molecules of this tile: rows whose molecule differs from the previous row's
+    if (tid < FZ_R) {
+        const int mol = a.row_mol[row0 + tid];
+        const int prev = tid > 0 ? a.row_mol[row0 + tid - 1] : -2;
+        const bool head = mol >= 0 && mol != prev;
+        const unsigned long long bal = __ballot(head);
+        if (lane == 0) mlist[128 + w] = __popcll(bal);         // wave 1 adds wave 0's count after the barrier
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (head) { mlist[130 + tid] = before; }          // provisional index within the wave
+        mlist[260 + tid] = head ? mol : -1;
+    }
+    __syncthreads();                         // also: every wave is done reading h0 from As
+    {
+        const AccBuf io = acc_buf<2 * D>(a.ij, row0, lrow, col);
+        const float bi = a.b ? a.b[col] : 0.f, bj = a.b ? a.b[D + col] : 0.f;
+        const int act = a.act_j;
+        FZ_FOR_ACC {
+            const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+            const float iv = bmp_sigmoid(acc[0][rb][reg] + bi);
+            const float jv = bmp_act(act, acc[1][rb][reg] + bj);
+            acc_st<2 * D>(io, rb, reg, iv, 0);
+            acc_st<2 * D>(io, rb, reg, jv, D);
+            Al[LOFF(rb, reg)] = a.row_w[row0 + r] * iv * jv;
+        }
+    }
+    if (tid < FZ_R && mlist[260 + tid] >= 0) {            // compact list: entry = (first row, molecule)
+        const int idx = mlist[130 + tid] + (tid >= 64 ? mlist[128] : 0);
+        mlist[2 * idx] = tid;
+        mlist[2 * idx + 1] = mlist[260 + tid];
+    }
+    __syncthreads();
+    const int nm = mlist[128] + mlist[129];
+    for (int task = tid; task < nm * D; task += 512) {
+        const int m = task / D, c = task % D;
+        const int r0 = mlist[2 * m], mol = mlist[2 * m + 1];
+        const int nr = a.mol_nrows[mol];
+        float sum = 0.f;
+        for (int r = r0; r < r0 + nr; ++r) sum += As[r * LD + c];
+        a.g[(size_t)mol * D + c] = sum;
+    }
+}
 #undef LOFF
 
 // ---------------------------------------------------------------------------------------------
@@ -882,4 +983,37 @@ extern "C" int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const f
     if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
     WGArgs g2{wdeg, nullptr, 4, 0, gda + 4 * d, 5 * d, 4, d, N, dbE, d, accumulate};
     return bmp_launch_wgrad(g2, ws, st);
+}
+
+// ---- readout forward on the tile machinery (d == o in {64, 128}; h0 absent or d wide) ----
+extern "C" int bmp_readout_tile_supported(int d, int d0, int o) {
+    return bmp_ggnn_step_supported(d) && o == d && (d0 == 0 || d0 == d);
+}
+
+static size_t ro_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + 400) * sizeof(float); }
+
+template <int D, bool HAS0>
+static int ro_launch(const ROArgs& a, int n_tiles, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_readout_tile_fwd<D, HAS0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)ro_lds_bytes(D));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const double rows = (double)n_tiles * FZ_R;
+    BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * (HAS0 ? 2.0 : 1.0) * D * 2.0 * D, 4.0 * rows * D * (HAS0 ? 4.0 : 3.0), st);
+    hipLaunchKernelGGL((k_readout_tile_fwd<D, HAS0>), dim3(n_tiles), dim3(512), ro_lds_bytes(D), st, a);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// As bmp_readout_fwd, with WT K4-packed and the row -> molecule map of the packed batch (row_mol [N], -1 = no molecule).
+extern "C" int bmp_readout_tile_fwd(const float* h, const float* h0, int n_tiles, int d, const float* WT, const float* b,
+                                    int act_j, const float* row_w, const int* row_mol, const int* mol_nrows, float* ij,
+                                    float* g, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && row_mol != nullptr);
+    ROArgs a{h, h0, WT, b, act_j, row_w, row_mol, mol_nrows, ij, g};
+    if (d == 128) return h0 ? ro_launch<128, true>(a, n_tiles, st) : ro_launch<128, false>(a, n_tiles, st);
+    return h0 ? ro_launch<64, true>(a, n_tiles, st) : ro_launch<64, false>(a, n_tiles, st);
 }

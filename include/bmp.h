@@ -125,6 +125,13 @@ int bmp_readout_bwd(const float* dg, const float* h, const float* h0, int n_tile
                     const float* Wnat, const float* ij, int act_j, const float* row_w, const int* mol_row0,
                     const int* mol_nrows, int n_mols, float* dh, float* dh0, float* dWT, float* db, float* ws,
                     size_t ws_floats, bmp_stream_t stream);
+/* The same forward as one kernel per tile when bmp_readout_tile_supported(d, d0, o) (d == o in {64, 128}, d0 in {0, d}):
+ * WT K4-packed as for bmp_ggnn_step_*, row_mol [N] = molecule of every packed row (-1: none).  Every molecule lies in
+ * one tile, whose workgroup takes its sum in a fixed order. */
+int bmp_readout_tile_supported(int d, int d0, int o);
+int bmp_readout_tile_fwd(const float* h, const float* h0, int n_tiles, int d, const float* WT, const float* b, int act_j,
+                         const float* row_w, const int* row_mol, const int* mol_nrows, float* ij, float* g,
+                         bmp_stream_t stream);
 
 /* GraphLinear on row tiles -- chainer_chemistry GraphLinear (models/ggnn.py:16,88,135,139;
  * nie_coattention.py:325-329): Y = act(X . WT + b); weight/bias gradients over N rows. */

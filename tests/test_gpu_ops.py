@@ -376,3 +376,35 @@ def test_ggnn_encoder_fused_variants(fn, batch, d, o, n_layers, tying, fused):
     (g * cg.float().to(dev())).sum().backward()
     for name, gr in grad_dict(enc).items():
         close(gr, p[name].grad, f"grad {name}")
+
+
+@pytest.mark.parametrize("d,with_h0,act", [(128, True, "identity"), (64, True, "tanh"), (128, False, "tanh")])
+def test_readout_tile_kernel_equals_gemm_plus_segment_sum(fn, batch, d, with_h0, act):
+    """bmp_readout_tile_fwd (one kernel per tile, sums taken in LDS) against bmp_readout_fwd (row GEMM + segment sum)
+    on the same inputs, and the gradients that flow through the saved ij of either."""
+    import dataclasses
+    store, _i1, _i2, pb = batch
+    pbd = to_dev(pb)
+    assert pbd.row_mol is not None
+    g = torch.Generator().manual_seed(d + with_h0)
+    mk = lambda *s_: (torch.randn(*s_, generator=g) * 0.3).to(dev())
+    h0_, x_ = mk(pb.n_rows, d), mk(pb.n_rows, d)
+    WT_, b_ = mk(d * (2 if with_h0 else 1), 2 * d), mk(2 * d)
+    cw = mk(pb.n_mols, d)
+    res = []
+    for tile in (True, False):
+        pbx = pbd if tile else dataclasses.replace(pbd, row_mol=None, _cache={})       # no map -> the two-kernel path
+        x, h0, WT, b = (t.clone().requires_grad_() for t in (x_, h0_, WT_, b_))
+        y = fn.ReadoutFn.apply(x, h0 if with_h0 else None, WT, b, pbx, fn.ACT[act])
+        (y * cw).sum().backward()
+        res.append((y, x.grad, h0.grad if with_h0 else None, WT.grad, b.grad))
+    rows = torch.zeros(pb.n_rows, dtype=torch.bool)
+    for r0, nr in zip(pb.mol_row0.tolist(), pb.mol_nrows.tolist()):
+        rows[r0:r0 + nr] = True
+    rows = rows.to(dev())
+    for name, a, b2 in zip(("g", "dh", "dh0", "dWT", "db"), res[0], res[1]):
+        if a is None:
+            continue
+        if name in ("dh", "dh0"):
+            a, b2 = a[rows], b2[rows]
+        close(a, b2, name)
