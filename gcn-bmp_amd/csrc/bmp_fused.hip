@@ -761,7 +761,8 @@ __global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Hs = lds;                         // [128 x LD]  h tile
     float* As = lds + FZ_R * LD;             // [128 x LD]  h0 tile -> w * sigmoid(i) * act_j(j)
-    int* mlist = (int*)(As + FZ_R * LD);     // [64 x 2] (first tile row, molecule) + [2] counts
+    int* mlist = (int*)(As + FZ_R * LD);     // [64 x 2] (first tile row, molecule) + [2] counts + scratch (see below)
+    float* rws = (float*)(mlist + 400);      // [128] row multiplicities of the tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
         *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
         if (HAS0) *(f32x4*)(As + r * LD + 4 * c4) = *(const f32x4*)(a.h0 + (size_t)(row0 + r) * D + 4 * c4);
     }
+    if (tid < FZ_R) rws[tid] = a.row_w[row0 + tid];
     const float* const Bh[2] = {a.WT + (size_t)(4 * hi) * 2 * D + 4 * col, a.WT + (size_t)(4 * hi) * 2 * D + 4 * (D + col)};
     const int ldw[2] = {2 * D, 2 * D};
     BPre<2> pre_h;
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
             const float jv = bmp_act(act, acc[1][rb][reg] + bj);
             acc_st<2 * D>(io, rb, reg, iv, 0);
             acc_st<2 * D>(io, rb, reg, jv, D);
-            Al[LOFF(rb, reg)] = a.row_w[row0 + r] * iv * jv;
+            Al[LOFF(rb, reg)] = rws[r] * iv * jv;
         }
     }
     if (tid < FZ_R && mlist[260 + tid] >= 0) {            // compact list: entry = (first row, molecule)
@@ -990,7 +992,7 @@ extern "C" int bmp_readout_tile_supported(int d, int d0, int o) {
     return bmp_ggnn_step_supported(d) && o == d && (d0 == 0 || d0 == d);
 }
 
-static size_t ro_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + 400) * sizeof(float); }
+static size_t ro_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + 400 + FZ_R) * sizeof(float); }
 
 template <int D, bool HAS0>
 static int ro_launch(const ROArgs& a, int n_tiles, hipStream_t st) {
