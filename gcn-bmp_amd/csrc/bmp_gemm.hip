@@ -536,8 +536,8 @@ static void wgrad_lds_plan(int N, int K, int Nn, int& S, int& rps) {
     const int tiles = ((K + 127) / 128) * ((Nn + 127) / 128);
     int want = 512 / tiles;                           // 2 workgroups per CU and NO second round: 7 tiles x 74 splits = 518
     if (want < 1) want = 1;                           // workgroups on 512 slots made a launch wait for six stragglers
-    int max_s = N / 256;                              // at least 256 rows (8 stages) per split
-    if (max_s < 1) max_s = 1;
+    int max_s = N / (tiles == 1 ? 128 : 256);         // at least 256 rows (8 stages) per split; a single-tile problem
+    if (max_s < 1) max_s = 1;                         // takes 128-row splits so that every CU gets two workgroups
     S = want < max_s ? want : max_s;
     if (S < 1) S = 1;
     rps = (N + S - 1) / S;
