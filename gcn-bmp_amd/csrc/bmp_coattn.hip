@@ -15,6 +15,8 @@
 
 #define CO_MAXN 128          // rows per molecule never exceed the tile size
 #define CO_MAXH 16
+#define CO_NT_BIG 1024     // threads per pair of the 96-row class in the backward
+#define CO_NT_FWD 512      // threads per pair in the forward (one launch sized by the largest class)
 
 struct CoArgs {
     const float* X1; const float* X2;          // [N1 x d], [N2 x d]
@@ -67,7 +69,7 @@ struct CoLds {
     float* Up; float* dPp; float* cmb;   // [256], [256 x H], [np] per-thread partial sums / combined row sums (backward)
 };
 
-__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd, int o = 0) {
+__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd, int o = 0, int nt = 256) {
     CoLds L;
     float* p = base;
     L.Cs = p; p += (size_t)np * ldc;
@@ -90,13 +92,13 @@ __device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, b
     L.cmb = p; if (bwd) p += np;
     // np == 128: SUB = 2, and the slots alias arrays that are dead by then (dots1|dots2 = 256, H1s|H2s = 256 x H)
     if (np >= 128) { L.Up = L.dots1; L.dPp = L.H1s; }
-    else { L.Up = p; if (bwd) p += 256; L.dPp = p; if (bwd) p += 256 * H; }
+    else { L.Up = p; if (bwd) p += nt; L.dPp = p; if (bwd) p += nt * H; }
     return L;
 }
 
-static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0) {
+static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0, int nt = 256) {
     return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 6 : 2) + 11 * (size_t)np + (bwd ? 2 * (size_t)o + np : 0) +
-           ((bwd && np < 128) ? 256 + 256 * (size_t)H : 0) + 8;
+           ((bwd && np < 128) ? nt + nt * (size_t)H : 0) + 8;
 }
 
 // column / row softmax statistics of C with multiplicities:
@@ -134,8 +136,9 @@ __device__ __forceinline__ float co_L1(const CoLds& L, int i, int j, int ldc) {
     return L.w1s[j] > 0.f ? bmp_exp(L.Cs[i * ldc + j] - L.rmax[i]) * L.invD1[i] : 0.f;
 }
 
-template <int HT>
-__global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
+template <int HT, int NT>
+__global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
+    constexpr int NW = NT / 64;
     constexpr int HN = HT > 0 ? HT : CO_MAXH;       // head count known at compile time (8, 4) or runtime (<16)
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const int b = a.order[a.order_off + blockIdx.x];
@@ -147,8 +150,8 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     const CoLds L = co_carve(lds_raw, a.np, ldc, H, false);
     const float cb = a.cbias[0];
 
-    for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
-    for (int idx = tid; idx < n2 * H; idx += 256) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
     if (tid < n1) L.w1s[tid] = a.w1[r1 + tid];
     if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
         const int i = tid - CO_MAXN;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     __syncthreads();
 
     // ---- energy tiles: S = Q2 . X1^T on the matrix cores, one 32x32 block per wave at a time ----
-    for (int blk = wave; blk < nb2 * nb1; blk += 4) {
+    for (int blk = wave; blk < nb2 * nb1; blk += NW) {
         const int bi = blk / nb1, bj = blk % nb1;
         int ia = bi * 32 + l31; ia = ia < n2 ? ia : n2 - 1;
         int ja = bj * 32 + l31; ja = ja < n1 ? ja : n1 - 1;
@@ -276,24 +279,47 @@ __global__ __launch_bounds__(256) void k_coattn_fwd(CoArgs a) {
     __syncthreads();
 
     // ---- pooled outputs: compact_k = sum_atoms w * alpha * j_layer(atoms)  (:368-369) ----
+    // thread (k group, side, column): the NT / 256 groups split the atoms, partial sums meet in LDS (C is dead by now)
     {
-        const int side = tid >> 7, t = tid & 127;
+        constexpr int KG = NT / 256;
+        const int kg = tid >> 8, side = (tid >> 7) & 1, t = tid & 127;
         const float* Z = side == 0 ? a.Z1 + (size_t)r1 * ZC : a.Z2 + (size_t)r2 * ZC;
         const float* al = side == 0 ? L.s1 : L.s2;
         const float* ww = side == 0 ? L.w1s : L.w2s;
         const int n = side == 0 ? n1 : n2;
+        const int chunk = (n + KG - 1) / KG, k_lo = kg * chunk, k_hi = (k_lo + chunk) < n ? (k_lo + chunk) : n;
         float* out = (side == 0 ? a.out1 : a.out2) + (size_t)b * o;
-        for (int c = t; c < o; c += 128) {
+        float* part = L.Cs;                     // [KG][2][128] per pass over the columns
+        for (int c0 = 0; c0 < o; c0 += 128) {
+            const int c = c0 + t;
             float acc = 0.f;
+            if (c < o) {
 #pragma unroll 8
-            for (int k = 0; k < n; ++k) acc += ww[k] * al[k] * Z[(size_t)k * ZC + c];
-            out[c] = acc;
+                for (int k = k_lo; k < k_hi; ++k) acc += ww[k] * al[k] * Z[(size_t)k * ZC + c];
+            }
+            if (KG == 1) {
+                if (c < o) out[c] = acc;
+            } else {
+                __syncthreads();
+                part[(kg * 2 + side) * 128 + t] = acc;
+                __syncthreads();
+                if (kg == 0 && c < o) {
+                    float v = part[side * 128 + t];
+#pragma unroll
+                    for (int g = 1; g < KG; ++g) v += part[(g * 2 + side) * 128 + t];
+                    out[c] = v;
+                }
+            }
         }
     }
 }
 
-template <int HT>
-__global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
+// NT threads per pair: the phases are strided loops, (row, chunk) decompositions and MFMA blocks per wave, so a bigger
+// pair takes more waves (a launch of a size class lasts about one workgroup's latency; a 96-row pair took 120 us with
+// 256 threads).  The per-row phases (one thread per atom of either side) use the first 2 * CO_MAXN threads.
+template <int HT, int NT>
+__global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
+    constexpr int NW = NT / 64;
     constexpr int HN = HT > 0 ? HT : CO_MAXH;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const int b = a.order[a.order_off + blockIdx.x];
@@ -303,14 +329,14 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     const int d = a.d, o = a.o, H = HT > 0 ? HT : a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const int n1p = nb1 * 32, n2p = nb2 * 32;
-    const CoLds L = co_carve(lds_raw, a.np, ldc, H, true, o);
+    const CoLds L = co_carve(lds_raw, a.np, ldc, H, true, o, NT);
 
     // ---- load the pair's saved state ----
-    for (int idx = tid; idx < n1 * H; idx += 256) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
-    for (int idx = tid; idx < n2 * H; idx += 256) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
-    for (int idx = tid; idx < n1 * H; idx += 256) L.H1s[idx] = a.H1[(size_t)r1 * H + idx];
-    for (int idx = tid; idx < n2 * H; idx += 256) L.H2s[idx] = a.H2[(size_t)r2 * H + idx];
-    for (int c = tid; c < o; c += 256) { L.do1[c] = a.dout1[(size_t)b * o + c]; L.do2[c] = a.dout2[(size_t)b * o + c]; }
+    for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
+    for (int idx = tid; idx < n1 * H; idx += NT) L.H1s[idx] = a.H1[(size_t)r1 * H + idx];
+    for (int idx = tid; idx < n2 * H; idx += NT) L.H2s[idx] = a.H2[(size_t)r2 * H + idx];
+    for (int c = tid; c < o; c += NT) { L.do1[c] = a.dout1[(size_t)b * o + c]; L.do2[c] = a.dout2[(size_t)b * o + c]; }
     if (tid < n1) { L.w1s[tid] = a.w1[r1 + tid]; L.s1[tid] = a.al1[r1 + tid]; }
     if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
         const int i = tid - CO_MAXN;
@@ -318,27 +344,27 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     }
     {
         const float* cg = a.Cbuf + a.coff[b];
-        for (int idx = tid; idx < n2p * ldc; idx += 256) { L.dSs[idx] = 0.f; }
-        for (int idx = tid; idx < n2 * n1; idx += 256) L.Cs[(idx / n1) * ldc + idx % n1] = cg[idx];
+        for (int idx = tid; idx < n2p * ldc; idx += NT) { L.dSs[idx] = 0.f; }
+        for (int idx = tid; idx < n2 * n1; idx += NT) L.Cs[(idx / n1) * ldc + idx % n1] = cg[idx];
     }
     __syncthreads();
 
     // ---- pooled-output backward: dJ = w*alpha*dout ; dot[k] = J[k,:] . dout ----
-    {   // each wave takes rows rbase, rbase+4, +8, +12 together: four independent row loads in flight
+    {   // each wave takes rows rbase, rbase + NW, + 2 NW, + 3 NW together: four independent row loads in flight
         const int nrows = n1 + n2;
-        for (int rbase = wave; rbase < nrows; rbase += 16) {
+        for (int rbase = wave; rbase < nrows; rbase += 4 * NW) {
             float dot[4] = {0.f, 0.f, 0.f, 0.f};
             for (int c = lane; c < o; c += 64) {
                 float zq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int row = rbase + 4 * q;
+                    const int row = rbase + NW * q;
                     const size_t gr = row < n1 ? (size_t)(r1 + row) : (size_t)(r2 + row - n1);
                     zq[q] = row < nrows ? (row < n1 ? a.Z1 : a.Z2)[gr * ZC + c] : 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int row = rbase + 4 * q;
+                    const int row = rbase + NW * q;
                     if (row < nrows) {
                         const bool s1 = row < n1;
                         const int k = s1 ? row : row - n1;
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = rbase + 4 * q;
+                const int row = rbase + NW * q;
                 const float dsum = wave_sum(dot[q]);
                 if (lane == 0 && row < nrows) (row < n1 ? L.dots1 : L.dots2)[row < n1 ? row : row - n1] = dsum;
             }
@@ -376,7 +402,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         float A1 = 0.f, A2 = 0.f;
         for (int j = 0; j < n1; ++j) A1 += L.w1s[j];
         for (int i = 0; i < n2; ++i) A2 += L.w2s[i];
-        for (int idx = tid; idx < n2 * n1; idx += 256) {
+        for (int idx = tid; idx < n2 * n1; idx += NT) {
             const int i = idx / n1, j = idx % n1;
             const float dc = L.w2s[i] / A2 * L.dots1[j] + L.w1s[j] / A1 * L.dots2[i];
             L.dSs[i * ldc + j] = dc * bmp_dact(a.act, L.Cs[i * ldc + j]);
@@ -384,7 +410,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         if (tid < 2 * H) a.dpart[(size_t)b * (2 * H + 1) + tid] = 0.f;
     } else {
     // dHpre[k,h] = ds_k * wa[h] * (1 - H^2) ; per-pair partial of dwa[h] = sum_k ds_k H[k,h]
-    for (int idx = tid; idx < (n1 + n2) * H; idx += 256) {
+    for (int idx = tid; idx < (n1 + n2) * H; idx += NT) {
         const int row = idx / H, h = idx % H;
         const int side = row < n1 ? 0 : 1;
         const int k = side == 0 ? row : row - n1;
@@ -405,12 +431,12 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
     co_stats(L, n1, n2, ldc);
     __syncthreads();
 
-    // ---- softmax-of-C backward, all 256 threads: thread (row, q) owns the q-th chunk of the other side's atoms.
+    // ---- softmax-of-C backward, all NT threads: thread (row, q) owns the q-th chunk of the other side's atoms.
     //      L1[j,i] = softmax over j (row i fixed):  dC1[i,j] = L1*(w2_i*g1[i,j] - w1_j*U1_i),  g1 = dH1[j,:].P2[i,:],
     //      U1_i = sum_j L1*w2_i*g1 ;  dP2[i,:] = dH2[i,:] + w2_i * sum_j L1 * dH1[j,:]      (and symmetrically L2).
     //      Partial sums go to per-thread LDS slots and are combined in a fixed order (reproducible). ----
     const int np_ = a.np;
-    const int SUB = 256 / np_;
+    const int SUB = NT / np_;
     const int prow = tid % np_, pq = tid / np_;
     {   // L1 path, pass 1
         float U = 0.f, dp[HN];
@@ -445,7 +471,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + tid];
         L.cmb[tid] = u;
     }
-    for (int idx = tid; idx < n2 * H; idx += 256) {       // dP2 -> dZ2
+    for (int idx = tid; idx < n2 * H; idx += NT) {       // dP2 -> dZ2
         const int i = idx / H, h = idx % H;
         float v = L.dH2s[idx];
         for (int q = 0; q < SUB; ++q) v += L.dPp[(q * np_ + i) * H + h];
@@ -501,7 +527,7 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
         for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + tid];
         L.cmb[tid] = u;
     }
-    for (int idx = tid; idx < n1 * H; idx += 256) {       // dP1 -> dZ1
+    for (int idx = tid; idx < n1 * H; idx += NT) {       // dP1 -> dZ1
         const int j = idx / H, h = idx % H;
         float v = L.dH1s[idx];
         for (int q = 0; q < SUB; ++q) v += L.dPp[(q * np_ + j) * H + h];
@@ -542,14 +568,14 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
             a.dZ2[(size_t)(r2 + i) * ZC + o + H] = dv2;
         }
         const float tot = wave_sum(dv2);
-        if (lane == 0) L.dots1[wave - 2] = tot;
+        if (lane == 0 && wave < 4) L.dots1[wave - 2] = tot;
     }
     __syncthreads();
     if (tid == 0) a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = L.dots1[0] + L.dots1[1];
 
     // ---- energy backward on the matrix cores: dQ2 = dS . X1 ; dX1 = dS^T . Q2 ----
     const int ncb = (d + 31) >> 5;
-    for (int blk = wave; blk < (nb2 + nb1) * ncb; blk += 4) {
+    for (int blk = wave; blk < (nb2 + nb1) * ncb; blk += NW) {
         const bool isq = blk < nb2 * ncb;
         const int bl = isq ? blk : blk - nb2 * ncb;
         const int br = bl / ncb, bc = bl % ncb;
@@ -588,8 +614,8 @@ __global__ __launch_bounds__(256) void k_coattn_bwd(CoArgs a) {
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static int co_set_lds(const void* fn, size_t bytes) {
-    static const void* done[8] = {nullptr};        // the six kernel instances: set once each, not per launch
-    for (int i = 0; i < 8; ++i) {
+    static const void* done[16] = {nullptr};       // the kernel instances in use: set once each, not per launch
+    for (int i = 0; i < 16; ++i) {
         if (done[i] == fn) return 0;
         if (done[i] == nullptr) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -629,7 +655,8 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         const int nt[3] = {n_tiles2, n_tiles1, n_tiles2};
         if ((rc = bmp_launch_rowgemm_multi(g, nt, 3, st))) return rc;
     }
-    const void* kf = H == 8 ? (const void*)k_coattn_fwd<8> : H == 4 ? (const void*)k_coattn_fwd<4> : (const void*)k_coattn_fwd<0>;
+    const void* kf = H == 8 ? (const void*)k_coattn_fwd<8, CO_NT_FWD> : H == 4 ? (const void*)k_coattn_fwd<4, CO_NT_FWD>
+                                                                              : (const void*)k_coattn_fwd<0, CO_NT_FWD>;
     if ((rc = co_set_lds(kf, 160 * 1024))) return rc;
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
@@ -645,9 +672,9 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         const size_t lds = co_lds_floats(a.np, a.ldc, H, false) * sizeof(float);
         BMP_REQUIRE(lds <= 160 * 1024);
         BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
-        if (H == 8) hipLaunchKernelGGL(k_coattn_fwd<8>, dim3(cnt[c]), dim3(256), lds, st, a);
-        else if (H == 4) hipLaunchKernelGGL(k_coattn_fwd<4>, dim3(cnt[c]), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL(k_coattn_fwd<0>, dim3(cnt[c]), dim3(256), lds, st, a);
+        if (H == 8) hipLaunchKernelGGL((k_coattn_fwd<8, CO_NT_FWD>), dim3(cnt[c]), dim3(CO_NT_FWD), lds, st, a);
+        else if (H == 4) hipLaunchKernelGGL((k_coattn_fwd<4, CO_NT_FWD>), dim3(cnt[c]), dim3(CO_NT_FWD), lds, st, a);
+        else hipLaunchKernelGGL((k_coattn_fwd<0, CO_NT_FWD>), dim3(cnt[c]), dim3(CO_NT_FWD), lds, st, a);
         BMP_LAUNCH_CHECK();
         off += cnt[c];
     }
@@ -703,8 +730,6 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     if ((e = hipMemsetAsync(dQ2, 0, ((size_t)N2 * d + (size_t)(N1 + N2) * ZC) * sizeof(float), st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(dX1, 0, (size_t)N1 * d * sizeof(float), st)) != hipSuccess) return (int)e;
     int rc;
-    const void* kb = H == 8 ? (const void*)k_coattn_bwd<8> : H == 4 ? (const void*)k_coattn_bwd<4> : (const void*)k_coattn_bwd<0>;
-    if ((rc = co_set_lds(kb, 160 * 1024))) return rc;
     CoArgs a; memset(&a, 0, sizeof(a));
     a.X1 = X1; a.X2 = X2; a.Q2 = Q2; a.Z1 = Z1; a.Z2 = Z2; a.ZC = ZC; a.w1 = w1; a.w2 = w2;
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2;
@@ -718,12 +743,22 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
         for (int c = 0; c < 4; ++c) {
             if (cnt[c] == 0) continue;
             a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
-            const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o) * sizeof(float);
+            // threads per pair by size class: a launch lasts about one workgroup's latency, so bigger pairs get more
+            // waves (np = 128 stays at 256: its per-thread partial-sum slots alias arrays sized for 256 threads)
+            const int nt = c <= 1 ? 512 : (c == 2 ? CO_NT_BIG : 256);
+            const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o, nt) * sizeof(float);
             BMP_REQUIRE(lds <= 160 * 1024);
             BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
-            if (H == 8) hipLaunchKernelGGL(k_coattn_bwd<8>, dim3(cnt[c]), dim3(256), lds, st, a);
-            else if (H == 4) hipLaunchKernelGGL(k_coattn_bwd<4>, dim3(cnt[c]), dim3(256), lds, st, a);
-            else hipLaunchKernelGGL(k_coattn_bwd<0>, dim3(cnt[c]), dim3(256), lds, st, a);
+#define CO_BWD_LAUNCH(HT_, NT_)                                                                              \
+            {                                                                                                \
+                if ((rc = co_set_lds((const void*)k_coattn_bwd<HT_, NT_>, 160 * 1024))) return rc;          \
+                hipLaunchKernelGGL((k_coattn_bwd<HT_, NT_>), dim3(cnt[c]), dim3(NT_), lds, st, a);           \
+            }
+#define CO_BWD_BY_NT(HT_)                                                                                    \
+            if (nt == 256) CO_BWD_LAUNCH(HT_, 256) else if (nt == 512) CO_BWD_LAUNCH(HT_, 512) else CO_BWD_LAUNCH(HT_, CO_NT_BIG)
+            if (H == 8) { CO_BWD_BY_NT(8) } else if (H == 4) { CO_BWD_BY_NT(4) } else { CO_BWD_BY_NT(0) }
+#undef CO_BWD_BY_NT
+#undef CO_BWD_LAUNCH
             BMP_LAUNCH_CHECK();
             off += cnt[c];
         }
