@@ -51,6 +51,12 @@ def _size_classes(nr1: np.ndarray, nr2: np.ndarray, device):
             torch.from_numpy(order_f).to(device), counts_f)
 
 
+def _cbuf_floats(n1: np.ndarray, n2: np.ndarray) -> np.ndarray:
+    """Floats a pair keeps between forward and backward: C (n2 x n1) and the softmax statistics of its columns and rows
+    (cmax, 1/D2 per side-1 atom; rmax, 1/D1 per side-2 atom) -- include/bmp.h, bmp_coattn_cbuf_floats."""
+    return n1 * n2 + 2 * (n1 + n2)
+
+
 def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
     """Row tensors and per-pair row ranges of the two sides.
 
@@ -67,7 +73,7 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
                 raise ValueError("co-attention needs as many side-2 as side-1 molecules")
             T1 = pb1.side_tiles[1]
             nr = pb1.mol_nrows_host
-            coff = np.concatenate(([0], np.cumsum(nr[:B] * nr[B:])))
+            coff = np.concatenate(([0], np.cumsum(_cbuf_floats(nr[:B], nr[B:]))))
             pb1._cache[key] = dict(
                 B=B, T1=T1, T2=pb1.side_tiles[2] - T1,
                 r1=pb1.mol_row0[:B].contiguous(), n1=pb1.mol_nrows[:B].contiguous(),
@@ -85,7 +91,7 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
     if pb1.n_mols != pb2.n_mols:
         raise ValueError("co-attention needs as many side-2 as side-1 molecules")
     nr1, nr2 = pb1.mol_nrows_host, pb2.mol_nrows_host
-    coff = np.concatenate(([0], np.cumsum(nr1 * nr2)))
+    coff = np.concatenate(([0], np.cumsum(_cbuf_floats(nr1, nr2))))
     m = dict(B=pb1.n_mols, T1=pb1.n_tiles, T2=pb2.n_tiles, r1=pb1.mol_row0, n1=pb1.mol_nrows, r2=pb2.mol_row0,
              n2=pb2.mol_nrows, coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
     m["order"], m["counts"], m["order_f"], m["counts_f"] = _size_classes(nr1, nr2, pb1.device)

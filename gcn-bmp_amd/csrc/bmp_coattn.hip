@@ -211,6 +211,11 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
         }
     } else {
     co_stats(L, n1, n2, ldc);
+    {   // the backward reloads these instead of walking C again (17 % of its time): kept behind the pair's C block
+        float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
+        if (tid < CO_MAXN) { if (tid < n1) { st[tid] = L.cmax[tid]; st[n1 + tid] = L.invD2[tid]; } }
+        else if (tid < 2 * CO_MAXN) { const int i = tid - CO_MAXN; if (i < n2) { st[2 * n1 + i] = L.rmax[i]; st[2 * n1 + n2 + i] = L.invD1[i]; } }
+    }
     __syncthreads();
 
     // ---- head projections: H1 = tanh(P1 + L1 . P2), H2 = tanh(P2 + L2 . P1)  (:352-362) ----
@@ -330,8 +335,12 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const int n1p = nb1 * 32, n2p = nb2 * 32;
     const CoLds L = co_carve(lds_raw, a.np, ldc, H, true, o, NT);
-
     // ---- load the pair's saved state ----
+    {   // column / row softmax statistics of C: saved by the forward behind the pair's C block
+        const float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
+        if (tid < CO_MAXN) { if (tid < n1) { L.cmax[tid] = st[tid]; L.invD2[tid] = st[n1 + tid]; } }
+        else if (tid < 2 * CO_MAXN) { const int i = tid - CO_MAXN; if (i < n2) { L.rmax[i] = st[2 * n1 + i]; L.invD1[i] = st[2 * n1 + n2 + i]; } }
+    }
     for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n1 * H; idx += NT) L.H1s[idx] = a.H1[(size_t)r1 * H + idx];
@@ -347,6 +356,28 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         for (int idx = tid; idx < n2p * ldc; idx += NT) { L.dSs[idx] = 0.f; }
         for (int idx = tid; idx < n2 * n1; idx += NT) L.Cs[(idx / n1) * ldc + idx % n1] = cg[idx];
     }
+    // B operands of this wave's first energy-backward block (rows of X1 or Q2 -- inputs, nothing of this kernel): asked
+    // for behind the loads of the saved state, used at the very end; the block otherwise opens with a global round trip while the matrix pipe waits
+    const int ncb = (d + 31) >> 5;
+    float pre[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) pre[t] = 0.f;
+    if (wave < (nb2 + nb1) * ncb) {
+        const bool isq = wave < nb2 * ncb;
+        const int bc = (isq ? wave : wave - nb2 * ncb) % ncb;
+        const int col = bc * 32 + l31;
+        const int colc = col < d ? col : d - 1;
+        const int kn = isq ? n1 : n2;
+        const float* src = isq ? a.X1 + (size_t)r1 * d : a.Q2 + (size_t)r2 * d;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = ks * 8 + 4 * hi + t;
+                pre[ks * 4 + t] = src[(size_t)(k < kn ? k : kn - 1) * d + colc];
+            }
+    }
+
     __syncthreads();
 
     // ---- pooled-output backward: dJ = w*alpha*dout ; dot[k] = J[k,:] . dout ----
@@ -428,7 +459,6 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         }
         a.dpart[(size_t)b * (2 * H + 1) + side * H + h] = acc;
     }
-    co_stats(L, n1, n2, ldc);
     __syncthreads();
 
     // ---- softmax-of-C backward, all NT threads: thread (row, q) owns the q-th chunk of the other side's atoms.
@@ -574,7 +604,6 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     if (tid == 0) a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = L.dots1[0] + L.dots1[1];
 
     // ---- energy backward on the matrix cores: dQ2 = dS . X1 ; dX1 = dS^T . Q2 ----
-    const int ncb = (d + 31) >> 5;
     for (int blk = wave; blk < (nb2 + nb1) * ncb; blk += NW) {
         const bool isq = blk < nb2 * ncb;
         const int bl = isq ? blk : blk - nb2 * ncb;
@@ -587,8 +616,20 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        int k_start = 0;
+        if (blk == wave) {                           // the rows requested at the top of the kernel
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int k = ks * 8 + 4 * hi + t;
+                    const float av = isq ? L.dSs[(br * 32 + l31) * ldc + k] : L.dSs[k * ldc + br * 32 + l31];
+                    acc = bmp_mfma(av, pre[ks * 4 + t], acc);
+                }
+            k_start = 32;
+        }
 #pragma unroll 4
-        for (int k0 = 0; k0 < knp; k0 += 8) {
+        for (int k0 = k_start; k0 < knp; k0 += 8) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int k = k0 + 4 * hi + t;
@@ -745,7 +786,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
             a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
             // threads per pair by size class: a launch lasts about one workgroup's latency, so bigger pairs get more
             // waves (np = 128 stays at 256: its per-thread partial-sum slots alias arrays sized for 256 threads)
-            const int nt = c <= 1 ? 512 : (c == 2 ? CO_NT_BIG : 256);
+            const int nt = c == 0 ? 256 : (c == 1 ? 512 : (c == 2 ? CO_NT_BIG : 256));
             const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o, nt) * sizeof(float);
             BMP_REQUIRE(lds <= 160 * 1024);
             BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);

@@ -179,7 +179,9 @@ int bmp_rowcorr_bwd(const float* de, const float* a, int o, const float* q, cons
  * ZC = bmp_coattn_zcols(o, H), zb [ZC] = [bj | 0], wa{1,2} [H], cbias [1].
  * `order` lists the pair ids grouped by size class (max(n1,n2) <= 32, 64, 96, 128) with n32..n128 the class
  * counts (sum = B): one launch per class, LDS sized by the class.
- * Saves Q2 [N2 x d], Z1/Z2 [N x ZC], Cbuf (pair b at coff[b]: n2 x n1), H1/H2 [N x H], al1/al2 [N]. */
+ * Saves Q2 [N2 x d], Z1/Z2 [N x ZC], H1/H2 [N x H], al1/al2 [N] and Cbuf: pair b owns n2*n1 + 2*(n1 + n2) floats at
+ * coff[b] -- C (n2 x n1, row-major), then the softmax statistics of C the backward reloads: cmax [n1], 1/D2 [n1]
+ * (column softmax over side-2 atoms), rmax [n2], 1/D1 [n2] (row softmax over side-1 atoms). */
 int bmp_coattn_zcols(int o, int H);
 int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act, int mode,
                        const float* w1, const int* r1, const int* n1, const float* w2, const int* r2, const int* n2,
