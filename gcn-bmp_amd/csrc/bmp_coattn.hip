@@ -16,6 +16,7 @@
 #define CO_MAXN 128          // rows per molecule never exceed the tile size
 #define CO_MAXH 16
 #define CO_NT_BIG 1024     // threads per pair of the 96-row class in the backward
+#define CO_DQ 4             // rows per wave and iteration in the backward's dot phase
 #define CO_NT_FWD 512      // threads per pair in the forward (one launch sized by the largest class)
 
 struct CoArgs {
@@ -381,20 +382,22 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     __syncthreads();
 
     // ---- pooled-output backward: dJ = w*alpha*dout ; dot[k] = J[k,:] . dout ----
-    {   // each wave takes rows rbase, rbase + NW, + 2 NW, + 3 NW together: four independent row loads in flight
+    {   // each wave takes CO_DQ rows (rbase + q NW) together: that many independent row loads in flight
         const int nrows = n1 + n2;
-        for (int rbase = wave; rbase < nrows; rbase += 4 * NW) {
-            float dot[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int c = lane; c < o; c += 64) {
-                float zq[4];
+        for (int rbase = wave; rbase < nrows; rbase += CO_DQ * NW) {
+            float dot[CO_DQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CO_DQ; ++q) dot[q] = 0.f;
+            for (int c = lane; c < o; c += 64) {
+                float zq[CO_DQ];
+#pragma unroll
+                for (int q = 0; q < CO_DQ; ++q) {
                     const int row = rbase + NW * q;
                     const size_t gr = row < n1 ? (size_t)(r1 + row) : (size_t)(r2 + row - n1);
                     zq[q] = row < nrows ? (row < n1 ? a.Z1 : a.Z2)[gr * ZC + c] : 0.f;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < CO_DQ; ++q) {
                     const int row = rbase + NW * q;
                     if (row < nrows) {
                         const bool s1 = row < n1;
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CO_DQ; ++q) {
                 const int row = rbase + NW * q;
                 const float dsum = wave_sum(dot[q]);
                 if (lane == 0 && row < nrows) (row < n1 ? L.dots1 : L.dots2)[row < n1 ? row : row - n1] = dsum;
