@@ -219,7 +219,7 @@ def main():
             # passes of this same command, committed under profiles/), not measurable from inside this process
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_hbm_traffic.json")))
                 key = {5: "k_ggnn_step_fwd<128, false>", 6: "k_ggnn_step_bwd<128, false>", 2: "k_wgrad_lds<false>",
                        1: "k_rowgemm<1, 4, 1, 0>"}.get(cls)
                 if key in pmc:
