@@ -97,6 +97,16 @@ def main():
          y=y.detach().numpy(), g1=g1.detach().numpy(), g2=g2.detach().numpy(), loss=loss.detach().numpy(),
          **{f"param:{k}": v.detach().numpy() for k, v in p.items()}, **grads_of(loss, p))
 
+    # ---- the other co-attention families on the same three pairs (GGNN 2 x 8 encoder, head 8 / 1) ------------
+    for k, attn in enumerate(("deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural")):
+        p = O.make_pair_params(790 + k, hidden_dim=8, out_dim=8, n_layers=2, attn=attn, head=8, dtype=torch.float64)
+        p = {kk: v.requires_grad_() for kk, v in p.items()}
+        y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn=attn)
+        loss = O.sigmoid_cross_entropy(y, T(label))
+        save(f"pair_attn_{attn.replace('-', '_')}.npz", atoms_1=a1, adj_1=j1, atoms_2=a2, adj_2=j2, label=label,
+             y=y.detach().numpy(), g1=g1.detach().numpy(), g2=g2.detach().numpy(), loss=loss.detach().numpy(),
+             **{f"param:{kk}": v.detach().numpy() for kk, v in p.items()}, **grads_of(loss, p))
+
 
 if __name__ == "__main__":
     main()

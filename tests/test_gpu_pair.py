@@ -290,3 +290,27 @@ def test_folded_fine_variants_through_the_pair_predictor(pairs, attn):
             assert gr is None or float(gr.abs().max()) == 0.0, name
             continue
         close(gr, ref, f"grad {name}")
+
+
+@pytest.mark.parametrize("attn", ["deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural"])
+def test_pair_golden_other_coattention(golden_dir, attn):
+    """Committed float64 vectors of every co-attention family (tests/golden/make_golden.py), reference call form
+    (four dense arrays)."""
+    import os
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict, grad_dict
+    z = np.load(os.path.join(golden_dir, f"pair_attn_{attn.replace('-', '_')}.npz"))
+    p = {k[6:]: z[k] for k in z.files if k.startswith("param:")}
+    model = build_pair_predictor(hidden_dim=8, out_dim=8, n_layers=2, attn=attn, head=8 if attn != "parallel" else 1).to(dev())
+    load_param_dict(model, p)
+    y = model(T(z["atoms_1"]), T(z["adj_1"]), T(z["atoms_2"]), T(z["adj_2"]))
+    close(y, T(z["y"]), "logits")
+    loss = model.loss(y, T(z["label"]).to(dev()))
+    close(loss, T(z["loss"]), "loss")
+    loss.backward()
+    for name, gr in grad_dict(model).items():
+        ref = T(z["grad:" + name])
+        if gr is None:
+            assert float(ref.abs().max()) == 0.0, name
+            continue
+        close(gr, ref, f"grad {name}", floor=1e-4 * float(ref.abs().max()) + 1e-7)

@@ -59,6 +59,21 @@ def test_golden_pair(golden_dir, name, enc, nl):
     _check_grads(loss, p, gref)
 
 
+ATTN_GOLDEN = ["deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural"]
+
+
+@pytest.mark.parametrize("attn", ATTN_GOLDEN)
+def test_golden_pair_other_coattention(golden_dir, attn):
+    z, p, gref = _load(golden_dir, f"pair_attn_{attn.replace('-', '_')}.npz")
+    y, g1, g2 = O.pair_forward(p, T(z["atoms_1"]), T(z["adj_1"]).double(), T(z["atoms_2"]), T(z["adj_2"]).double(),
+                               n_layers=2, attn=attn)
+    assert torch.allclose(y, T(z["y"]), rtol=1e-12, atol=1e-13)
+    assert torch.allclose(g1, T(z["g1"]), rtol=1e-12, atol=1e-13) and torch.allclose(g2, T(z["g2"]), rtol=1e-12, atol=1e-13)
+    loss = O.sigmoid_cross_entropy(y, T(z["label"]))
+    assert torch.allclose(loss, T(z["loss"]), rtol=1e-12)
+    _check_grads(loss, p, gref)
+
+
 # ------------------------------------------------------------------------------------------ KATs
 def _ggnn_params(d=8, o=8, n_layers=3, seed=3, **kw):
     dr = O._Draw(seed, torch.float64, 0.2)
