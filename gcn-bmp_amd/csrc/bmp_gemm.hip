@@ -189,6 +189,137 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row GEMM, both operands through LDS: 128 rows x 128 columns per workgroup (4 waves, each all 128 rows x 32 columns).
+// The direct form above reads its weight fragments straight from L2 one k-step ahead; vmcnt retires in order, so that
+// read queues behind the NEXT chunk's row loads (HBM latency) at every chunk start and the matrix pipe waits
+// (SQ_WAIT_INST_ANY: half of the wave cycles, MFMA busy 0.38 on the readout GEMM).  Here a 64-deep chunk of the rows AND
+// of the weights is requested at the top of the previous chunk, lands during its MFMAs and is written to LDS at the
+// chunk boundary; inside a chunk the waves only wait on LDS.  Needs Nout, ldw multiples of 4 and 16-byte aligned weights.
+// ---------------------------------------------------------------------------------------------
+#define RGB_LDB 132
+template <int EPI>
+__device__ __forceinline__ void rowgemm_lds_body(const RGArgs& a, int bx, int by, float* lds) {
+    constexpr int RB = 4, R = 128, NT = 128;
+    float* la = lds;                         // [128][BMP_LDS_LD]  rows x k
+    float* lb = lds + R * BMP_LDS_LD;        // [64][RGB_LDB]      k x columns
+    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = bx * R, n0 = by * NT;
+
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+
+    f32x4 sa[8], sb[8];                      // the chunk in flight: 128 x 64 rows, 64 x 128 weights
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_chunk = [&](int s_, int k0_) {
+        const float* __restrict__ X = a.s[s_].X;
+        const float* __restrict__ X2 = a.s[s_].X2;
+        const float* __restrict__ Wt = a.s[s_].Wt;
+        const int ldx = a.s[s_].ldx, ldx2 = a.s[s_].ldx2, ldw = a.s[s_].ldw, K = a.s[s_].K;
+        const int kc = (K - k0_) < 64 ? (K - k0_) : 64;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256;
+            const int r = idx >> 4, c4 = idx & 15;
+            f32x4 v = zero4;
+            if (4 * c4 < kc) {
+                v = *(const f32x4*)(X + (size_t)(row0 + r) * ldx + k0_ + 4 * c4);
+                if (X2) v *= *(const f32x4*)(X2 + (size_t)(row0 + r) * ldx2 + k0_ + 4 * c4);
+            }
+            sa[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256;
+            const int k = idx >> 5, c4 = idx & 31;
+            const int col = n0 + 4 * c4;
+            sb[it] = (k < kc && col < a.Nout) ? *(const f32x4*)(Wt + (size_t)(k0_ + k) * ldw + col) : zero4;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256;
+            *(f32x4*)(&la[(idx >> 4) * BMP_LDS_LD + 4 * (idx & 15)]) = sa[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = tid + it * 256;
+            *(f32x4*)(&lb[(idx >> 5) * RGB_LDB + 4 * (idx & 31)]) = sb[it];
+        }
+    };
+    load_chunk(0, 0);
+    store_chunk();
+    __syncthreads();
+    for (int s = 0; s < a.nsrc; ++s) {
+        const int K = a.s[s].K;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int kc = (K - k0) < 64 ? (K - k0) : 64;
+            int cs = s, ck0 = k0 + 64;
+            if (ck0 >= K) { cs = s + 1; ck0 = 0; }
+            const bool more = cs < a.nsrc;
+            if (more) load_chunk(cs, ck0);
+            f32x4 a0[RB], a1[RB];
+            float b0[4], b1[4];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a0[rb] = *(const f32x4*)(&la[(rb * 32 + l31) * BMP_LDS_LD + 4 * hi]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b0[t] = lb[(4 * hi + t) * RGB_LDB + wc * 32 + l31];
+            for (int kk = 0; kk < kc; kk += 8) {
+                if (kk + 8 < kc) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b1[t] = lb[(kk + 8 + 4 * hi + t) * RGB_LDB + wc * 32 + l31];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a1[rb] = *(const f32x4*)(&la[(rb * 32 + l31) * BMP_LDS_LD + kk + 8 + 4 * hi]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) acc[rb] = bmp_mfma(a0[rb][t], b0[t], acc[rb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a0[rb] = a1[rb];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b0[t] = b1[t];
+            }
+            if (more) {
+                __syncthreads();
+                store_chunk();
+                __syncthreads();
+            }
+        }
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col < a.Nout) {
+        const RGCol cc = rg_col(a, col);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + rb * 32 + bmp_acc_row(reg, lane);
+                rg_epilogue<EPI>(a, cc, row, col, acc[rb][reg]);
+            }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_rowgemm_lds(RGArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[128 * BMP_LDS_LD + 64 * RGB_LDB];
+    rowgemm_lds_body<EPI>(a, blockIdx.x, blockIdx.y, lds);
+}
+
+static bool rowgemm_lds_ok(const RGArgs& a) {
+    if ((a.Nout & 3) != 0) return false;
+    for (int s = 0; s < a.nsrc; ++s)
+        if ((a.s[s].ldw & 3) != 0 || ((uintptr_t)a.s[s].Wt & 15) != 0) return false;
+    return true;
+}
+
 template <int WR, int RB, int CBW, int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[WR * RB * 32 * BMP_LDS_LD];
@@ -217,6 +348,7 @@ static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
         // problems that do not even give every CU one 128-row workgroup take 64-row workgroups: the launch is one
         // round either way, and its duration is one workgroup's latency
         if (n_tiles * ny <= 256) hipLaunchKernelGGL((k_rowgemm<1, 2, 1, EPI>), dim3(2 * n_tiles, ny), dim3(256), 0, st, a);
+        else if (rowgemm_lds_ok(a)) hipLaunchKernelGGL((k_rowgemm_lds<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_rowgemm<1, 4, 1, EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
     }
     BMP_LAUNCH_CHECK();
