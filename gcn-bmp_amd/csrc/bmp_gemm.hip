@@ -1,5 +1,6 @@
 // fp32-MFMA GEMM building blocks for gfx950: the row GEMM (atom-row tiles x weights) and the
 // weight-gradient GEMM (reduction over atom rows).  See bmp_kernels.h for the contracts.
+#include <stdlib.h>
 #include <string.h>
 #include "bmp_kernels.h"
 
@@ -314,6 +315,8 @@ __global__ __launch_bounds__(256) void k_rowgemm_lds(RGArgs a) {
 }
 
 static bool rowgemm_lds_ok(const RGArgs& a) {
+    static const bool off = getenv("BMP_ROWGEMM_DIRECT") != nullptr;      // tests compare the two forms
+    if (off) return false;
     if ((a.Nout & 3) != 0) return false;
     for (int s = 0; s < a.nsrc; ++s)
         if ((a.s[s].ldw & 3) != 0 || ((uintptr_t)a.s[s].Wt & 15) != 0) return false;
