@@ -1,19 +1,26 @@
 #!/usr/bin/env python
 """Headline benchmark: drug-pairs/sec, fwd+bwd(+Adam), binary-DDI GGNN d=128 + Nie co-attention.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one training step over one batch of 1024 drug pairs per GPU (workload C2/C5 of
-SURVEY.md 8(d)): both molecules of every pair encoded by the 4-step GGNN, Nie co-attention, MLP,
-sigmoid cross entropy, backward, one gradient all-reduce (N > 1), Adam.  Packed batches are
-resident in HBM before the timed region (the collate is the reference's host-side
-``concat_mols`` step); every molecule INSTANCE is encoded (no per-batch de-duplication).
-Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel class
-(HIP events, measured in this run) and a CPU baseline (the oracle on the host cores).
+A "step" is one training step over one batch of 1024 drug pairs per GPU: both molecules of every pair encoded, co-attention,
+link predictor, sigmoid cross entropy, backward, one gradient all-reduce (N > 1), Adam.  Every molecule INSTANCE is encoded
+(no per-batch de-duplication).  Configurations: c2 (default, the metric's configuration; c5 is c2 at N = 8)
+GGNN 4-step d=128 tied + Nie; c3 RelGCN 3x128 + Nie; c4 GGNN 4-step d=256 + MLP(37), multi-label store.
+
+Rank 0 prints ONE JSON line:
+  value         resident leg: K timed steps over packed batches already in HBM (all batches of one epoch, cycled)
+  end_to_end    one epoch with the reference's per-iteration collate inside the timed region (train_ddi_modify.py:280,
+                295-296): a fresh permutation, per step the host plan (size arithmetic), one pinned H2D copy and the device
+                kernel that writes the packed batch from the HBM-resident drug store
+  batch32       c2 at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end
+  roofline      the dominant kernel and its class, HIP events around every launch, measured in this run
+  cpu_baseline  the oracle (dense restatement) on the host cores: same model, batch 32; more: C1 and batch 256
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -28,55 +35,79 @@ import numpy as np          # noqa: E402
 import torch                # noqa: E402
 import torch.distributed as dist   # noqa: E402
 
-D, T_STEPS, HEAD, O = 128, 4, 8, 128
+HEAD = 8
 PAIRS_PER_GPU = 1024
-N_DISTINCT_BATCHES = 8
 PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
 
+CONFIGS = {
+    "c2": dict(encoder="ggnn", d=128, o=128, layers=4, attn="nie", class_num=1, store="binary",
+               workload="C2: full binary DDI set (544 drugs, 147696 pairs), GGNN 4-step d=128 tied + Nie co-attention "
+                        "(head 8, tanh) + MLP(32,16), fwd+bwd+Adam"),
+    "c3": dict(encoder="relgcn", d=128, o=128, layers=3, attn="nie", class_num=1, store="binary",
+               workload="C3: full binary DDI set, RelGCN 3-layer d=128 (scale_adj) + atoms tap + Nie co-attention + MLP(32,16), "
+                        "fwd+bwd+Adam"),
+    "c4": dict(encoder="ggnn", d=256, o=256, layers=4, attn=None, class_num=37, store="multilabel",
+               workload="C4: 37-class multi-label DDI (1704 drugs, 192000 pairs), GGNN 4-step d=256 tied + MLP(32,16) -> 37, "
+                        "fwd+bwd+Adam"),
+}
 
-def algorithmic_flops_per_pair(n_atoms_per_pair: float, d=D, T=T_STEPS, o=O, head=HEAD, n1=None, n2=None):
-    """fwd per atom-step 26 d^2 (message 8 d^2 + GRU 18 d^2), readout 6 d^2 per atom,
-    Nie co-attention, MLP; fwd+bwd = 3 x fwd.  Real atoms only (no pad/dead rows, no folding credit).
-    The readout counts ONCE: the fine co-attention ignores g_1 / g_2 (nie_coattention.py:335-370), so the readout
-    is computed forward (as the reference does) but no gradient ever reaches it -- there is no readout backward."""
-    half = n_atoms_per_pair / 2.0
-    ggnn = 26.0 * d * d * n_atoms_per_pair * T
-    readout = 6.0 * d * o * n_atoms_per_pair
-    co = 2.0 * (half * d * d + half * half * d + n_atoms_per_pair * d * o + 2 * n_atoms_per_pair * head * d)
-    mlp = 2.0 * (2 * o * 32 + 32 * 16 + 16)
-    return 3.0 * (ggnn + co + mlp) + readout
+KERNEL_NAMES = {16: "k_rowgemm / k_rowgemm_lds (fp32 MFMA row GEMM)", 17: "k_rowgemm_multi", 18: "k_readout_tile_fwd",
+                32: "k_wgrad_lds<false> (fp32 MFMA weight-gradient GEMM)", 33: "k_wgrad_lds<true>",
+                34: "k_wgrad_lds<false> one-hot (embedding gradient)", 35: "k_wgrad (direct)", 36: "k_wgrad_lds_multi",
+                64: "k_coattn_fwd", 65: "k_coattn_bwd", 80: "k_ggnn_step_fwd<D, false>", 81: "k_ggnn_step_fwd<D, true>",
+                82: "k_relgcn_layer_fwd", 96: "k_ggnn_step_bwd<D, false>", 97: "k_ggnn_step_bwd<D, true>",
+                98: "k_relgcn_layer_bwd"}
+CLASS_NAMES = {1: "row GEMMs", 2: "weight-gradient GEMMs", 3: "gathers", 4: "co-attention pair kernels",
+               5: "fused step / layer forward", 6: "fused step / layer backward"}
+# rocprofv3 kernel names of the keys above (profiles/*_pmc_hbm_traffic.json), {D} = hidden width
+PMC_NAMES = {32: "k_wgrad_lds<false>", 33: "k_wgrad_lds<true>", 36: "k_wgrad_lds_multi", 80: "k_ggnn_step_fwd<{D}, false>",
+             81: "k_ggnn_step_fwd<{D}, true>", 96: "k_ggnn_step_bwd<{D}, false>", 97: "k_ggnn_step_bwd<{D}, true>",
+             82: "k_relgcn_layer_fwd<{D}>", 98: "k_relgcn_layer_bwd<{D}>", 17: "k_rowgemm_multi", 18: "k_readout_tile_fwd<{D}, true>"}
 
 
-def algorithmic_bytes_per_pair(n_atoms_per_pair: float, n_edges_per_pair: float, d=D, T=T_STEPS):
-    """SURVEY.md 8(d) compulsory-traffic model: 2 n d (20 T + 40) + index bytes."""
-    return n_atoms_per_pair * d * (20.0 * T + 40.0) + 16.0 * T * (n_atoms_per_pair / 2 + 1 + n_edges_per_pair / 2) \
-        + 4.0 * n_atoms_per_pair
+def algorithmic_flops_per_pair(cfg, n_pair: float):
+    """SURVEY.md 8(d), real atoms only (no pad / dead rows, no folding credit), fwd+bwd = 3 x fwd.
+    GGNN: 26 d^2 per atom-step (message 8 d^2 + GRU 18 d^2), readout 6 d o per atom; RelGCN: 10 d^2 per atom-layer,
+    readout 4 d o.  With a fine co-attention the readout counts ONCE: it ignores g_1 / g_2 (nie_coattention.py:335-370),
+    so the readout runs forward as in the reference but no gradient ever reaches it."""
+    d, o, L = cfg["d"], cfg["o"], cfg["layers"]
+    half = n_pair / 2.0
+    if cfg["encoder"] == "ggnn":
+        enc, readout = 26.0 * d * d * n_pair * L, 6.0 * d * o * n_pair
+    else:
+        enc, readout = 10.0 * d * d * n_pair * L, 4.0 * d * o * n_pair
+    mlp = 2.0 * (2 * o * 32 + 32 * 16 + 16 * cfg["class_num"])
+    if cfg["attn"]:
+        co = 2.0 * (half * d * d + half * half * d + n_pair * d * o + 2 * n_pair * HEAD * d)
+        return 3.0 * (enc + co + mlp) + readout
+    return 3.0 * (enc + readout + mlp)
 
 
-def cpu_baseline(store, idx1, idx2, label, seconds=12.0):
-    """The oracle (oracle/ref_cpu.py, dense op-for-op restatement of the reference) timed on the
-    host cores: same model, fwd+bwd+Adam, the reference's default batch of 32 pairs
-    (train_ddi_modify.py:196), for about `seconds` of wall time."""
+def algorithmic_bytes_per_pair(cfg, n_pair: float, e_pair: float):
+    """SURVEY.md 8(d) compulsory-traffic model: n d (20 L + 28 [+ 12 with co-attention]) + index bytes."""
+    d, L = cfg["d"], cfg["layers"]
+    return n_pair * d * (20.0 * L + 28.0 + (12.0 if cfg["attn"] else 0.0)) + 16.0 * L * (n_pair / 2 + 1 + e_pair / 2) + 4.0 * n_pair
+
+
+def oracle_steps(store, idx1, idx2, label, B, seconds, hidden, layers, attn, class_num=1, max_steps=10 ** 9, warm=2):
+    """The oracle (oracle/ref_cpu.py, dense op-for-op restatement of the reference) fwd+bwd+Adam on the host cores for
+    about `seconds`; returns (pairs/s over the timed steps, timed steps, seconds used)."""
     from oracle import ref_cpu as O_
     from bmp import synth
-    # the GPU box exposes all host cores but grants a 16-core share per GPU: more threads only thrash
-    torch.set_num_threads(min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
-    p = O_.make_pair_params(777, hidden_dim=D, out_dim=O, n_layers=T_STEPS, attn="nie", head=HEAD, dtype=torch.float32,
-                            bias_scale=0.0)
-    names = sorted(p)
-    params = [p[n].requires_grad_() for n in names]
+    p = O_.make_pair_params(777, hidden_dim=hidden, out_dim=hidden, n_layers=layers, attn=attn, head=HEAD, class_num=class_num,
+                            dtype=torch.float32, bias_scale=0.0)
+    params = [p[n].requires_grad_() for n in sorted(p)]
     state = [dict(m=torch.zeros_like(x), v=torch.zeros_like(x)) for x in params]
-    B = 32
-    done, t_used, step = 0, 0.0, 0
+    times, step = [], 0
     while True:
         sl = slice(step * B, (step + 1) * B)
         a1, j1 = synth.concat_mols([store[k] for k in idx1[sl]])
         a2, j2 = synth.concat_mols([store[k] for k in idx2[sl]])
-        t = torch.from_numpy(label[sl].reshape(-1, 1))
+        t = torch.from_numpy(label[sl].reshape(len(a1), -1))
         t0 = time.perf_counter()
-        y, _, _ = O_.pair_forward(p, torch.from_numpy(a1), torch.from_numpy(j1), torch.from_numpy(a2),
-                                  torch.from_numpy(j2), n_layers=T_STEPS, attn="nie")
+        y, _, _ = O_.pair_forward(p, torch.from_numpy(a1), torch.from_numpy(j1), torch.from_numpy(a2), torch.from_numpy(j2),
+                                  n_layers=layers, attn=attn)
         loss = O_.sigmoid_cross_entropy(y, t)
         grads = torch.autograd.grad(loss, params, allow_unused=True)
         grads = [g if g is not None else torch.zeros_like(x) for g, x in zip(grads, params)]
@@ -84,24 +115,43 @@ def cpu_baseline(store, idx1, idx2, label, seconds=12.0):
             O_.chainer_adam_step(params, grads, state, step + 1)
         dt = time.perf_counter() - t0
         step += 1
-        if step > 2:                     # 2 warm-up steps
-            done += B
-            t_used += dt
-        if t_used >= seconds or (step + 1) * B > len(idx1):
+        if step > warm:
+            times.append(dt)
+        if sum(times) >= seconds or len(times) >= max_steps or (step + 1) * B > len(idx1):
             break
-    return dict(value=done / t_used, unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{done} pairs ({step - 2} timed steps of batch {B}, dense oracle fwd+bwd+Adam, fp32, "
-                       f"{t_used:.1f} s) of the same workload")
+    return B * len(times) / sum(times), len(times), sum(times), B / float(np.median(times))
+
+
+def cpu_baseline(cfg, store, idx1, idx2, label):
+    """`cpu_baseline`: the bench's own model at the reference's default batch of 32 (train_ddi_modify.py:196), ~10 s.
+    `more` (binary configs only): C1 (GGNN 2-step d=16 + MLP, batch 32, the first 256 pairs)
+    and the C2 model at batch 256."""
+    # the GPU box exposes all host cores but grants a 16-core share per GPU: more threads only thrash
+    torch.set_num_threads(min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    cores = torch.get_num_threads()
+    v, n, s, med = oracle_steps(store, idx1, idx2, label, 32, 10.0, cfg["d"], cfg["layers"], cfg["attn"], cfg["class_num"])
+    out = dict(value=round(v, 2), unit="pairs/s", cores=cores, kind="port",
+               sample=f"{32 * n} pairs ({n} timed steps of batch 32, dense oracle fwd+bwd+Adam, fp32, {s:.1f} s) of the same "
+                      f"workload; median step {med:.1f} pairs/s; torch {torch.__version__}")
+    more = None
+    if cfg["store"] == "binary" and cfg["encoder"] == "ggnn":
+        v1, n1, s1, m1 = oracle_steps(store, idx1[:256 + 96], idx2[:256 + 96], label[:256 + 96], 32, 3.0, 16, 2, None, warm=3)
+        v2, n2, s2, m2 = oracle_steps(store, idx1, idx2, label, 256, 8.0, cfg["d"], cfg["layers"], cfg["attn"], warm=1, max_steps=10)
+        more = {"C1 GGNN 2-step d=16 + MLP, batch 32": dict(value=round(v1, 1), median=round(m1, 1), steps=n1, seconds=round(s1, 2)),
+                "C2 model, batch 256": dict(value=round(v2, 2), median=round(m2, 2), steps=n2, seconds=round(s2, 2))}
+    return out, more
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-class", type=int, default=0, help="kernel class for the roofline leg (0 = auto)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end, batch-32 and roofline legs")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,31 +186,40 @@ def main():
     from bmp.dp import FlatAdam
     L = _lib.lib()
 
-    # ---- workload: the full binary DDI pair list, global batch = 1024 pairs x world -------------------
-    store = synth.make_store()
+    # ---- workload: the drug store lives in HBM; a batch is a slice of the pair permutation ---------------
+    if cfg["store"] == "binary":
+        store = synth.make_store()
+        idx1, idx2, label = synth.make_pairs()
+    else:
+        store = synth.make_store(1704, seed=2018)
+        idx1, idx2, label = synth.make_multilabel_pairs()
+    label = label.reshape(len(idx1), -1)
     ms = packed.MolStore(store)
-    idx1, idx2, label = synth.make_pairs()
+    dstore = packed.DeviceMolStore(ms, dev)
     gb = PAIRS_PER_GPU * world
-    batches, n_atoms, n_edges = [], 0, 0
-    for k in range(N_DISTINCT_BATCHES):
-        lo = k * gb + rank * PAIRS_PER_GPU
-        sl = slice(lo, lo + PAIRS_PER_GPU)
-        pb = packed.pack_from_store(ms, [idx1[sl], idx2[sl]], device=dev)
-        batches.append((pb, torch.from_numpy(label[sl].reshape(-1, 1)).to(dev)))
-        n_atoms += pb.n_real_atoms
-        n_edges += pb.n_edges
-    atoms_per_pair = n_atoms / (N_DISTINCT_BATCHES * PAIRS_PER_GPU)
-    edges_per_pair = n_edges / (N_DISTINCT_BATCHES * PAIRS_PER_GPU)
+    steps_per_epoch = len(idx1) // gb
+
+    def collate(i1, i2, lab, k, B=PAIRS_PER_GPU, gbatch=None):
+        """Global batch k of the pair list (i1, i2, lab): this rank's shard, packed on the device."""
+        lo = k * (gbatch or B * world) + rank * B
+        return packed.pack_from_store_device(dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B])
+
+    batches = [collate(idx1, idx2, label, k) for k in range(steps_per_epoch)]      # one epoch, resident
+    n_atoms = sum(pb.n_real_atoms for pb, _ in batches)
+    n_edges = sum(pb.n_edges for pb, _ in batches)
+    n_rows = sum(pb.n_rows for pb, _ in batches)
+    atoms_per_pair = n_atoms / (len(batches) * PAIRS_PER_GPU)
+    edges_per_pair = n_edges / (len(batches) * PAIRS_PER_GPU)
 
     torch.manual_seed(777)
-    model = build_pair_predictor(hidden_dim=D, out_dim=O, n_layers=T_STEPS, attn="nie", head=HEAD).to(dev)
+    model = build_pair_predictor(hidden_dim=cfg["d"], out_dim=cfg["o"], n_layers=cfg["layers"], attn=cfg["attn"], head=HEAD,
+                                 encoder=cfg["encoder"], class_num=cfg["class_num"]).to(dev)
     opt = FlatAdam(model, alpha=1e-3)
     opt.broadcast_parameters(0)
     if force_pg:
         opt.world = 2            # takes the all-reduce branch (a one-rank sum; the folded 1/2 only rescales the updates)
 
-    def step(i, collective=True):
-        pb, t = batches[i % N_DISTINCT_BATCHES]
+    def train_step(pb, t, collective=True):
         y = opt.functional_forward(pb)          # parameters = views of the flat buffer, ONE gradient tensor
         loss = model.loss(y, t)
         loss.backward()
@@ -175,86 +234,148 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    value = PAIRS_PER_GPU * world * args.steps / dt
+    def timed(n_steps, body):
+        """barrier + synchronize, n_steps x body(i), barrier + synchronize; returns (max over ranks, this rank) seconds."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            body(i)
+        fence()
+        mine = time.perf_counter() - t0
+        tt = torch.tensor([mine], device=dev, dtype=torch.float64)
+        if world > 1:
+            allr = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(allr, tt)
+            every = [float(x.item()) for x in allr]
+        else:
+            every = [mine]
+        return max(every), every
 
-    # ---- roofline leg: HIP events around every launch of the dominant kernel class, same workload ------
-    roof = None
+    # ---- resident leg (the metric): packed batches already in HBM ---------------------------------------
+    last = {}
+    def resident(i):
+        last["loss"] = train_step(*batches[i % len(batches)])
+    for i in range(args.warmup):
+        resident(i)
+    dt, every = timed(args.steps, lambda i: resident(args.warmup + i))
+    value = gb * args.steps / dt
+    loss_val = float(last["loss"].item())
+    rank_ms = None if world == 1 else dict(min=round(1e3 * min(every) / args.steps, 3), max=round(1e3 * max(every) / args.steps, 3))
+
+    # ---- end-to-end leg: one epoch, fresh permutation, collate inside the timed region --------------------
+    e2e = b32 = None
+    if not args.no_extras:
+        host_ms = []
+
+        def epoch_body(state):
+            def body(i):
+                if i == 0:          # the reference's SerialIterator shuffles once per epoch
+                    perm = np.random.RandomState(1000 + state["epoch"]).permutation(len(idx1))
+                    state["p"] = (idx1[perm], idx2[perm], label[perm])
+                t0 = time.perf_counter()
+                pb, t = collate(*state["p"], i, B=state["B"])
+                host_ms.append(time.perf_counter() - t0)
+                train_step(pb, t)
+            return body
+        st = dict(epoch=0, B=PAIRS_PER_GPU)
+        body = epoch_body(st)
+        for i in range(3):
+            body(i)
+        host_ms.clear()
+        dt_e, _ = timed(steps_per_epoch, body)
+        e2e = dict(value=round(gb * steps_per_epoch / dt_e, 1), unit="pairs/s", steps=steps_per_epoch,
+                   ms_per_step=round(1e3 * dt_e / steps_per_epoch, 3), ratio_to_resident=round(gb * steps_per_epoch / dt_e / value, 4),
+                   host_collate_ms_per_batch=round(1e3 * float(np.mean(host_ms)), 3),
+                   what="one epoch: fresh permutation, per step host plan + pinned H2D (plan table, labels, pair metadata) + "
+                        "bmp_collate_emit from the HBM-resident store, then the training step; nothing pre-packed")
+        if args.config == "c2" and world == 1:
+            st = dict(epoch=1, B=32)
+            body = epoch_body(st)
+            for i in range(10):
+                body(i)
+            n32 = 300
+            dt_32, _ = timed(n32, lambda i: body(i + 1))
+            b32 = dict(value=round(32 * n32 / dt_32, 1), unit="pairs/s", steps=n32, ms_per_step=round(1e3 * dt_32 / n32, 3),
+                       what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end")
+
+    # ---- roofline leg: HIP events around every launch (all classes), same workload, rank 0 -------------------
+    roof = whole = None
     if rank == 0:
-        per_class = {}
-        classes = [args.prof_class] if args.prof_class else [1, 2, 5, 6]
-        n_prof = 3
-        out = (ctypes.c_double * 3)()
-        for cls in classes:
-            L.bmp_prof_start(cls)
-            for i in range(n_prof):
-                step(i, collective=False)
-            torch.cuda.synchronize()
-            n = L.bmp_prof_stop(out)
-            if n:
-                per_class[cls] = dict(launches=n / n_prof, ms=out[0] / n_prof, flops=out[1] / n_prof, bytes=out[2] / n_prof)
-        if per_class:
-            cls = max(per_class, key=lambda c: per_class[c]["ms"])
-            pc = per_class[cls]
-            pbs = [b[0] for b in batches[:n_prof]]
-            real_frac = sum(p.n_real_atoms for p in pbs) / sum(p.n_rows for p in pbs)
-            # executed flops count every row of the packed layout (virtual pad + dead rows);
-            # algorithmic flops count real atoms only
-            alg_flops = pc["flops"] * real_frac
-            achieved = alg_flops / (pc["ms"] * 1e-3) / 1e12
-            names = {1: "k_rowgemm (fp32 MFMA row GEMM)", 2: "k_wgrad_lds (fp32 MFMA weight-gradient GEMM)",
-                     5: "k_ggnn_step_fwd", 6: "k_ggnn_step_bwd"}
-            # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 --pmc
-            # passes of this same command, committed under profiles/), not measurable from inside this process
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_hbm_traffic.json")))
-                key = {5: "k_ggnn_step_fwd<128, false>", 6: "k_ggnn_step_bwd<128, false>", 2: "k_wgrad_lds<false>",
-                       1: "k_rowgemm<1, 4, 1, 0>"}.get(cls)
-                if key in pmc:
-                    # counters are in KiB; gfx950 tallies a 16-byte-per-lane streaming read at half its bytes
-                    # (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE is doubled, WRITE_SIZE taken as is
-                    traffic = round((2.0 * pmc[key]["FETCH_SIZE_per_launch"] + pmc[key]["WRITE_SIZE_per_launch"]) * 1024)
-            except (OSError, ValueError):
-                pass
-            roof = dict(bound="mfma", achieved=round(achieved, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_TFLOPS, 4), traffic=traffic, kernel=names.get(cls, str(cls)),
-                        launches_per_step=pc["launches"], avg_launch_us=round(1e3 * pc["ms"] / pc["launches"], 2),
-                        alg_gflop_per_launch=round(alg_flops / pc["launches"] / 1e9, 4),
-                        class_ms_per_step={str(k): round(v["ms"], 3) for k, v in per_class.items()},
-                        measured="HIP events around every launch of the class, 3 steps after the timed region")
-        alg_f = algorithmic_flops_per_pair(atoms_per_pair)
-        alg_b = algorithmic_bytes_per_pair(atoms_per_pair, edges_per_pair)
+        alg_f = algorithmic_flops_per_pair(cfg, atoms_per_pair)
+        alg_b = algorithmic_bytes_per_pair(cfg, atoms_per_pair, edges_per_pair)
         whole = dict(alg_mflop_per_pair=round(alg_f / 1e6, 1), alg_kb_per_pair=round(alg_b / 1e3, 1),
                      f32_frac=round(value / world * alg_f / (PEAK_F32_TFLOPS * 1e12), 4),
                      hbm_frac=round(value / world * alg_b / (PEAK_HBM_GBS * 1e9), 5))
+    if rank == 0 and not args.no_extras:
+        n_prof, cap = 6, 64
+        key = (ctypes.c_int * cap)(); cnt = (ctypes.c_int * cap)()
+        ms_ = (ctypes.c_double * cap)(); fl = (ctypes.c_double * cap)(); by = (ctypes.c_double * cap)()
+        L.bmp_prof_start(-1)
+        for i in range(n_prof):
+            train_step(*batches[i % len(batches)], collective=False)
+        torch.cuda.synchronize()
+        nk = L.bmp_prof_collect(key, cnt, ms_, fl, by, cap)
+        rows_prof = sum(batches[i % len(batches)][0].n_rows for i in range(n_prof))
+        real_frac = sum(batches[i % len(batches)][0].n_real_atoms for i in range(n_prof)) / rows_prof
+        kern = {key[i]: dict(launches=cnt[i] / n_prof, ms=ms_[i] / n_prof, flops=fl[i] / n_prof) for i in range(nk)}
+        if kern:
+            def entry(ks, name):
+                msum = sum(kern[k]["ms"] for k in ks)
+                lsum = sum(kern[k]["launches"] for k in ks)
+                # the launchers state executed flops over every packed row (virtual pad + dead rows included);
+                # algorithmic flops count real atoms only
+                alg = sum(kern[k]["flops"] for k in ks) * real_frac
+                ach = alg / (msum * 1e-3) / 1e12 if msum > 0 else 0.0
+                return dict(kernel=name, launches_per_step=round(lsum, 2), avg_launch_us=round(1e3 * msum / max(lsum, 1e-9), 2),
+                            ms_per_step=round(msum, 4), alg_gflop_per_launch=round(alg / max(lsum, 1e-9) / 1e9, 4),
+                            achieved=round(ach, 3), frac=round(ach / PEAK_F32_TFLOPS, 4))
+            top = max(kern, key=lambda k: kern[k]["ms"])
+            cls = top // 16
+            k_e = entry([top], KERNEL_NAMES.get(top, str(top)))
+            c_e = entry([k for k in kern if k // 16 == cls], CLASS_NAMES.get(cls, str(cls)))
+            # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 --pmc passes of
+            # this command, committed under profiles/); taken only from a profile of THIS library version and kernel name
+            traffic = None
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+                try:
+                    pmc = json.load(open(path))
+                except (OSError, ValueError):
+                    continue
+                name = PMC_NAMES.get(top, "").replace("{D}", str(cfg["d"]))
+                if pmc.get("_bmp_version") == L.bmp_version() and pmc.get("_config", "c2") == args.config and name in pmc:
+                    # counters are in KiB; gfx950 tallies a 16-byte-per-lane streaming read at half its bytes
+                    # (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE is doubled, WRITE_SIZE taken as is
+                    traffic = round((2.0 * pmc[name]["FETCH_SIZE_per_launch"] + pmc[name]["WRITE_SIZE_per_launch"]) * 1024)
+                    break
+            roof = dict(bound="mfma", achieved=k_e["achieved"], peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=k_e["frac"],
+                        traffic=traffic, **{k: v for k, v in k_e.items() if k not in ("achieved", "frac")}, kernel_class=c_e,
+                        per_kernel_ms_per_step={KERNEL_NAMES.get(k, str(k)): round(v["ms"], 4) for k, v in
+                                                sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
+                        measured=f"HIP events around every launch of every instrumented kernel, {n_prof} steps after the timed "
+                                 "region, same stream; achieved = algorithmic flops (real atoms only) / event time")
 
-    cpu = None
+    cpu = cpu_more = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(store, idx1, idx2, label)
+        cpu, cpu_more = cpu_baseline(cfg, store, idx1, idx2, label)
 
     if rank == 0:
-        print(json.dumps({
-            "metric": "drug-pairs/sec fwd+bwd, binary-DDI GGNN d=128", "value": round(value, 1), "unit": "pairs/s",
+        names = {"c2": "drug-pairs/sec fwd+bwd, binary-DDI GGNN d=128", "c3": "drug-pairs/sec fwd+bwd, binary-DDI RelGCN d=128",
+                 "c4": "drug-pairs/sec fwd+bwd, 37-class multi-label DDI GGNN d=256"}
+        line = {
+            "metric": names[args.config], "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: full binary DDI set (544 drugs, 147696 pairs), GGNN 4-step d=128 tied + "
-                                   "Nie co-attention (head 8, tanh) + MLP(32,16), fwd+bwd+Adam, "
-                                   f"{PAIRS_PER_GPU} pairs/GPU/step, every molecule instance encoded",
+            "config": {"workload": cfg["workload"] + f", {PAIRS_PER_GPU} pairs/GPU/step, every molecule instance encoded; the "
+                                   f"{len(batches)} batches of one epoch resident in HBM, cycled",
                        "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": gb, "parallelism": f"dp{world}",
-                       "atoms_per_pair": round(atoms_per_pair, 2), "loss": round(float(loss.item()), 5)},
-            "roofline": roof, "whole_step": whole, "cpu_baseline": cpu}))
+                       "atoms_per_pair": round(atoms_per_pair, 2), "real_row_fraction": round(n_atoms / n_rows, 4),
+                       "loss": round(loss_val, 5)},
+            "roofline": roof, "whole_step": whole, "end_to_end": e2e, "batch32": b32, "cpu_baseline": cpu}
+        if cpu_more:
+            line["cpu_baseline_more"] = cpu_more
+        if rank_ms:
+            line["rank_ms_per_step"] = rank_ms
+        print(json.dumps(line))
     if world > 1 or force_pg:
         dist.barrier()
         dist.destroy_process_group()

@@ -22,6 +22,7 @@ SIGNATURES = {
     "bmp_tile_rows": (_I, []),
     "bmp_prof_start": (_I, [_I]),
     "bmp_prof_stop": (_I, [_P]),
+    "bmp_prof_collect": (_I, [_P, _P, _P, _P, _P, _I]),
     "bmp_embed_fwd": (_I, [_P, _P, _I, _I, _P, _P]),
     "bmp_embed_bwd_ws_floats": (_Z, [_I, _I, _I]),
     "bmp_embed_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, _P]),
@@ -61,6 +62,9 @@ SIGNATURES = {
     "bmp_rowcorr_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "bmp_dense_count": (_I, [_P, _I, _I, _P, _P, _P]),
     "bmp_dense_to_csr": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "bmp_collate_plan": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P]),
+    "bmp_collate_pair_meta": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "bmp_collate_emit": (_I, [_P, _I] + [_P] * 16 + [_P]),
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),
     "bmp_mlp_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -29,6 +29,7 @@ form in tests/test_packed.py.
 """
 from __future__ import annotations
 
+from ctypes import c_void_p as _c_void_p
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -152,7 +153,7 @@ class PackedMolBatch:
 def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
               e_dst: np.ndarray, e_src: np.ndarray, e_typ: np.ndarray, e_val: np.ndarray,
               side_of_inst: np.ndarray, n_sides: int, R: int, device,
-              dense_maps_flat: Optional[List[np.ndarray]] = None) -> PackedMolBatch:
+              dense_maps_flat: Optional[List[np.ndarray]] = None, n_real_atoms: Optional[int] = None) -> PackedMolBatch:
     """Common placement step: bin-pack instances into tiles (per side), remap rows
     and edges, build CSR + transposed CSR, upload."""
     I = len(inst_nrows)
@@ -212,7 +213,8 @@ def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
         side_tiles=tuple(side_tiles), side_mols=tuple(side_mols),
         dense_map=dmaps[0] if dmaps is not None and len(dmaps) == 1 else None,
         dense_maps=dmaps,
-        n_real_atoms=int((flat_w == 1).sum()), n_edges=int(len(e_dst)),
+        # every instance is its real rows + ONE virtual pad row (whose weight may happen to be 1: not a real atom)
+        n_real_atoms=int((inst_nrows - 1).sum()) if n_real_atoms is None else int(n_real_atoms), n_edges=int(len(e_dst)),
         max_rows_per_mol=int(inst_nrows.max()) if I else 0,
         mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[7],
     )
@@ -408,5 +410,156 @@ def pack_from_dense_device(atom_arrays: Sequence, adjs: Sequence[torch.Tensor], 
         csr_ptr=iv[1], csr_col=col[:E], csr_val=val[:E], csrT_ptr=iv[2], csrT_col=colT[:E], csrT_val=valT[:E],
         mol_row0=iv[3], mol_nrows=iv[4], side_tiles=tuple(side_tiles), side_mols=tuple(side_mols),
         dense_map=dmaps[0] if len(dmaps) == 1 else None, dense_maps=dmaps,
-        n_real_atoms=int((flat_w == 1).sum()), n_edges=E, max_rows_per_mol=int(inst_nrows.max()) if I else 0,
+        n_real_atoms=int((inst_nrows - 1).sum()), n_edges=E, max_rows_per_mol=int(inst_nrows.max()) if I else 0,
         mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[-1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The per-iteration collate on the device (train_ddi_modify.py:280 SerialIterator + :295-296 concat_mols):
+# the drug store lives in HBM, a batch is (idx1, idx2) -> one host planning call (size arithmetic only,
+# bmp_collate_plan), one small H2D copy, one kernel (bmp_collate_emit).  csrc/bmp_collate.hip.
+# ---------------------------------------------------------------------------------------------------------
+def _i32p(a: np.ndarray):
+    return _c_void_p(a.__array_interface__["data"][0])       # (ndarray.ctypes.data_as costs ~60 us per call)
+
+
+def collate_plan_host(st_nrows: np.ndarray, st_nedges: np.ndarray, sides: Sequence[np.ndarray], R: int = DEFAULT_R,
+                      pad_to: Optional[Sequence[int]] = None, tab: Optional[np.ndarray] = None):
+    """bmp_collate_plan on host arrays (no device work): returns (tab int32 [6*I], side_tiles, side_mols,
+    n_tiles, n_edges, n_real_atoms, max_rows)."""
+    from . import _lib
+    L = _lib.lib()
+    mids = np.ascontiguousarray(np.concatenate([np.asarray(s) for s in sides]), dtype=np.int32)
+    side_ptr = np.zeros(len(sides) + 1, dtype=np.int32)
+    np.cumsum([len(s) for s in sides], out=side_ptr[1:])
+    I = int(side_ptr[-1])
+    if tab is None:
+        tab = np.empty(6 * I, dtype=np.int32)
+    side_tiles = np.zeros(len(sides) + 1, dtype=np.int32)
+    totals = np.zeros(4, dtype=np.int64)
+    pt = None if pad_to is None else np.ascontiguousarray(pad_to, dtype=np.int32)
+    _lib.check(L.bmp_collate_plan(_i32p(st_nrows), _i32p(st_nedges), len(st_nrows), _i32p(mids), _i32p(side_ptr), len(sides),
+                                  None if pt is None else _i32p(pt), R, _i32p(tab), _i32p(side_tiles), _i32p(totals)),
+               "bmp_collate_plan")
+    return (tab, tuple(int(x) for x in side_tiles), tuple(int(x) for x in side_ptr), int(totals[0]), int(totals[1]),
+            int(totals[2]), int(totals[3]))
+
+
+class DeviceMolStore:
+    """The drug store resident in HBM: per molecule its atom ids and local CSR / transposed CSR, sorted as a packed
+    batch sorts them (destination row, source row, bond type).  ~0.3 MB for the 544 drugs of the binary DDI set."""
+
+    N_STAGE = 8        # pinned staging buffers in flight (a buffer is reused only after its copy has completed)
+
+    def __init__(self, store: MolStore, device):
+        self.host = store
+        self.device = torch.device(device)
+        M = store.n_mols
+        self.st_nrows = np.ascontiguousarray(store.nrows, dtype=np.int32)
+        self.st_nedges = np.ascontiguousarray(store.nedges, dtype=np.int32)
+        rowoff = np.zeros(M + 1, dtype=np.int64); np.cumsum(store.nrows, out=rowoff[1:])
+        eoff = np.zeros(M + 1, dtype=np.int64); np.cumsum(store.nedges, out=eoff[1:])
+        mol_of_edge = np.repeat(np.arange(M, dtype=np.int64), store.nedges)
+
+        def local_csr(major, minor):
+            order = np.lexsort((store.e_typ, minor, major, mol_of_edge))
+            col = ((minor[order] << 2) | store.e_typ[order]).astype(np.int32)
+            deg = np.bincount(rowoff[mol_of_edge] + major, minlength=int(rowoff[-1]))
+            rend = np.cumsum(deg) - np.repeat(eoff[:-1], store.nrows)            # end of the row's entries, local
+            return col, rend.astype(np.int32)
+
+        col, rend = local_csr(store.e_dst, store.e_src)
+        colT, rendT = local_csr(store.e_src, store.e_dst)
+        host = [rowoff.astype(np.int32), eoff.astype(np.int32), store.atom_flat.astype(np.int32), rend, rendT, col, colT]
+        self.host_arrays = host
+        if self.device.type == "cuda":
+            buf = torch.from_numpy(np.concatenate(host)).to(self.device)
+            self.dev, o = [], 0
+            for a in host:
+                self.dev.append(buf[o:o + len(a)]); o += len(a)
+            self._stage = [None] * self.N_STAGE
+            self._events = [None] * self.N_STAGE
+            self._k = 0
+
+    def _staging(self, n_ints: int) -> torch.Tensor:
+        k = self._k
+        self._k = (k + 1) % self.N_STAGE
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        if self._stage[k] is None or self._stage[k].numel() < n_ints:
+            self._stage[k] = torch.empty(max(n_ints, 1 << 15), dtype=torch.int32).pin_memory()
+        self._cur = k
+        return self._stage[k]
+
+    def _staged(self) -> None:
+        ev = self._events[self._cur]
+        if ev is None:
+            ev = self._events[self._cur] = torch.cuda.Event()
+        ev.record()
+
+
+def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], R: int = DEFAULT_R,
+                           pad_to: Optional[Sequence[int]] = None, labels: Optional[np.ndarray] = None):
+    """pack_from_store with the store resident on the GPU: the host only does the size arithmetic (zero-padding width
+    per side, tile placement, entry bases: ``bmp_collate_plan``), one pinned H2D copy carries the plan (and the
+    batch's labels and co-attention metadata), and one kernel writes the packed arrays (``bmp_collate_emit``).
+    Bit-identical to ``pack_from_store`` (tests/test_gpu_collate.py).  Returns the batch, or (batch, labels on the
+    device) when ``labels`` (int array, one row per pair) is given."""
+    from . import _lib
+    from ._lib import check, ptr, stream
+    L = _lib.lib()
+    dev = dstore.device
+    if dev.type != "cuda":
+        raise ValueError("pack_from_store_device needs the store on a GPU (no CPU fallback: use pack_from_store)")
+    n_sides = len(sides)
+    I = int(sum(len(s) for s in sides))
+    B = len(sides[0])
+    paired = n_sides == 2 and len(sides[1]) == B
+    n_tab = 6 * I + (6 * I) % 2                       # keeps the int64 block 8-byte aligned
+    n_meta = 8 * B if paired else 0
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+    n_lab = 0 if lab is None else lab.size
+    st = dstore._staging(n_tab + n_meta + n_lab)
+    st_np = st.numpy()
+    tab, side_tiles, side_mols, n_tiles, E, n_real, max_rows = collate_plan_host(
+        dstore.st_nrows, dstore.st_nedges, sides, R, pad_to, tab=st_np[:6 * I])
+    counts, ctotal = None, 0
+    if paired:
+        cnt = np.zeros(4, dtype=np.int32); ct = np.zeros(1, dtype=np.int64)
+        check(L.bmp_collate_pair_meta(_i32p(st_np), I, B, side_tiles[1], R, _i32p(st_np[n_tab:]), _i32p(cnt), _i32p(ct)),
+              "bmp_collate_pair_meta")
+        counts, ctotal = [int(c) for c in cnt], int(ct[0])
+    if lab is not None:
+        st_np[n_tab + n_meta:n_tab + n_meta + n_lab] = lab
+    n_up = n_tab + n_meta + n_lab
+    up = torch.empty(n_up, dtype=torch.int32, device=dev)
+    up.copy_(st[:n_up], non_blocking=True)
+    dstore._staged()
+    N = n_tiles * R
+    ibuf = torch.empty(3 * N + 2 + 2 * E, dtype=torch.int32, device=dev)
+    fbuf = torch.empty(N + 2 * E, dtype=torch.float32, device=dev)
+    atom_id, csr_ptr, csr_col = ibuf[:N], ibuf[N:2 * N + 1], ibuf[2 * N + 1:2 * N + 1 + E]
+    o = 2 * N + 1 + E
+    csrT_ptr, csrT_col, row_mol = ibuf[o:o + N + 1], ibuf[o + N + 1:o + N + 1 + E], ibuf[o + N + 1 + E:o + 2 * N + 1 + E]
+    row_w, csr_val, csrT_val = fbuf[:N], fbuf[N:N + E], fbuf[N + E:]
+    d = dstore.dev
+    check(L.bmp_collate_emit(ptr(up), I, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(d[5]), ptr(d[6]),
+                             ptr(atom_id), ptr(row_w), ptr(row_mol), ptr(csr_ptr), ptr(csr_col), ptr(csr_val), ptr(csrT_ptr),
+                             ptr(csrT_col), ptr(csrT_val), stream()), "bmp_collate_emit")
+    nrows_host = st_np[I:2 * I].astype(np.int64)
+    pb = PackedMolBatch(
+        R=R, n_tiles=n_tiles, n_mols=I, atom_id=atom_id, row_w=row_w, csr_ptr=csr_ptr, csr_col=csr_col, csr_val=csr_val,
+        csrT_ptr=csrT_ptr, csrT_col=csrT_col, csrT_val=csrT_val, mol_row0=up[:I], mol_nrows=up[I:2 * I],
+        side_tiles=side_tiles, side_mols=side_mols, n_real_atoms=n_real, n_edges=E, max_rows_per_mol=max_rows,
+        mol_nrows_host=nrows_host, row_mol=row_mol)
+    if paired:
+        m = up[n_tab:n_tab + n_meta]
+        top = max(k for k in range(4) if counts[k])
+        counts_f = [0, 0, 0, 0]; counts_f[top] = B
+        pb._cache["pair_meta"] = dict(
+            B=B, T1=side_tiles[1], T2=side_tiles[2] - side_tiles[1], coff=m[:2 * B].view(torch.int64), r1=m[2 * B:3 * B],
+            n1=m[3 * B:4 * B], r2=m[4 * B:5 * B], n2=m[5 * B:6 * B], order=m[6 * B:7 * B], order_f=m[7 * B:8 * B],
+            counts=counts, counts_f=counts_f, ctotal=ctotal)
+    if lab is None:
+        return pb
+    return pb, up[n_tab + n_meta:].view(np.asarray(labels).shape if np.asarray(labels).ndim > 1 else (-1,))

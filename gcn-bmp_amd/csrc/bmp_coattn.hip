@@ -715,7 +715,7 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
         a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
         const size_t lds = co_lds_floats(a.np, a.ldc, H, false) * sizeof(float);
         BMP_REQUIRE(lds <= 160 * 1024);
-        BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
+        BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st, BMP_KID_COATTN_FWD);
         if (H == 8) hipLaunchKernelGGL((k_coattn_fwd<8, CO_NT_FWD>), dim3(cnt[c]), dim3(CO_NT_FWD), lds, st, a);
         else if (H == 4) hipLaunchKernelGGL((k_coattn_fwd<4, CO_NT_FWD>), dim3(cnt[c]), dim3(CO_NT_FWD), lds, st, a);
         else hipLaunchKernelGGL((k_coattn_fwd<0, CO_NT_FWD>), dim3(cnt[c]), dim3(CO_NT_FWD), lds, st, a);
@@ -792,7 +792,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
             const int nt = c == 0 ? 256 : (c == 1 ? 512 : (c == 2 ? CO_NT_BIG : 256));
             const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o, nt) * sizeof(float);
             BMP_REQUIRE(lds <= 160 * 1024);
-            BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st);
+            BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st, BMP_KID_COATTN_BWD);
 #define CO_BWD_LAUNCH(HT_, NT_)                                                                              \
             {                                                                                                \
                 if ((rc = co_set_lds((const void*)k_coattn_bwd<HT_, NT_>, 160 * 1024))) return rc;          \

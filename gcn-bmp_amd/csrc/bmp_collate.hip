@@ -1,0 +1,209 @@
+// The reference's per-iteration collate (SerialIterator + converter=concat_mols, train_ddi_modify.py:280,295-296) for a
+// drug store that lives in HBM.  A batch of drug pairs is index work only: the store holds every molecule's atom ids
+// and its local CSR / transposed CSR (sorted by destination, source, bond type inside the molecule); a packed batch
+// (bmp/packed.py) is those per-molecule arrays shifted by the molecule's first packed row, because molecules own
+// disjoint, contiguous row ranges and the batch CSR order (row, source row, bond type) is the per-molecule order of
+// the molecules taken in row order.  So no sort is needed per batch:
+//   * bmp_collate_plan (HOST, no device work): the size arithmetic -- per-side zero-padding width A, first-fit-decreasing
+//     placement of the instances into 128-row tiles (the same placement as bmp.packed._bin_pack, which the tests pin it
+//     against), edge base of every instance, dead rows behind the last instance of a tile, and the co-attention's
+//     per-pair metadata (C-block offsets, size-class orders).  O(I log I) on a few thousand small integers.
+//   * bmp_collate_emit (DEVICE): one wavefront per molecule instance writes atom_id, row_w, row_mol, csr_ptr/col/val and
+//     csrT_ptr/col/val.  Integer / byte work, HBM bound (~12 bytes per row and ~16 per bond written, the store reads hit L2).
+// The result is bit-identical to bmp.packed.pack_from_store (tests/test_gpu_collate.py).
+#include <algorithm>
+#include <vector>
+#include "bmp_common.h"
+
+namespace {
+
+// leftmost bin with capacity >= s: max segment tree over bin capacities
+struct FirstFit {
+    int n, base;
+    std::vector<int> t;
+    FirstFit(int n_, int cap) : n(n_) {
+        base = 1;
+        while (base < n) base <<= 1;
+        t.assign(2 * base, 0);
+        for (int i = 0; i < n; ++i) t[base + i] = cap;
+        for (int i = base - 1; i >= 1; --i) t[i] = std::max(t[2 * i], t[2 * i + 1]);
+    }
+    int take(int s, int* off_before, int R) {
+        int i = 1;
+        while (i < base) i = (t[2 * i] >= s) ? 2 * i : 2 * i + 1;
+        const int b = i - base;
+        *off_before = R - t[i];
+        t[i] -= s;
+        for (i >>= 1; i >= 1; i >>= 1) t[i] = std::max(t[2 * i], t[2 * i + 1]);
+        return b;
+    }
+    int cap(int b) const { return t[base + b]; }
+};
+
+}  // namespace
+
+// Layout of the plan table `tab` (int32, 6 * I entries): row0[I] | nrows[I] | mid[I] | ebase[I] | padw[I] | ndead[I].
+//   row0  first packed row of the instance          nrows real atoms + 1 (the virtual pad row)
+//   mid   molecule of the store                     ebase first CSR entry of the instance
+//   padw  multiplicity of the virtual pad row = A[side] - n (concat_mols zero-padding)
+//   ndead dead rows that follow the instance (non-zero only for the last instance of a tile)
+// side_ptr [n_sides + 1]: instance ranges of the batch sides in `mids`; pad_to [n_sides] or NULL (pad to the side's max).
+// side_tiles [n_sides + 1] (out): tile boundaries of the sides.  totals (out): n_tiles, n_edges, n_real_atoms,
+// max rows of an instance.
+extern "C" int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n_store, const int* mids, const int* side_ptr,
+                                int n_sides, const int* pad_to, int R, int* tab, int* side_tiles, long long* totals) {
+    BMP_REQUIRE(st_nrows && st_nedges && mids && side_ptr && tab && side_tiles && totals && n_sides >= 1 && R >= 1);
+    const int I = side_ptr[n_sides];
+    BMP_REQUIRE(I >= 1 && side_ptr[0] == 0);
+    int* row0 = tab; int* nrows = tab + I; int* mid = tab + 2 * (size_t)I; int* ebase = tab + 3 * (size_t)I;
+    int* padw = tab + 4 * (size_t)I; int* ndead = tab + 5 * (size_t)I;
+    long long n_real = 0, n_edges = 0;
+    int max_rows = 0;
+    for (int i = 0; i < I; ++i) {
+        BMP_REQUIRE(mids[i] >= 0 && mids[i] < n_store);
+        mid[i] = mids[i];
+        nrows[i] = st_nrows[mids[i]];
+        BMP_REQUIRE(nrows[i] >= 1 && nrows[i] <= R);
+        n_real += nrows[i] - 1;
+        n_edges += st_nedges[mids[i]];
+        max_rows = std::max(max_rows, nrows[i]);
+        ndead[i] = 0;
+    }
+    int tile0 = 0;
+    side_tiles[0] = 0;
+    std::vector<int> order, cnt(R + 2);
+    for (int s = 0; s < n_sides; ++s) {
+        const int lo = side_ptr[s], hi = side_ptr[s + 1], n = hi - lo;
+        BMP_REQUIRE(n >= 1);
+        int A = 0;
+        for (int i = lo; i < hi; ++i) A = std::max(A, nrows[i] - 1);
+        if (pad_to) { BMP_REQUIRE(pad_to[s] >= A); A = pad_to[s]; }
+        for (int i = lo; i < hi; ++i) padw[i] = A - (nrows[i] - 1);
+        // stable order by decreasing size (counting sort; == numpy argsort(-sizes, kind="stable"))
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int i = lo; i < hi; ++i) ++cnt[R - nrows[i] + 1];
+        for (int k = 1; k <= R + 1; ++k) cnt[k] += cnt[k - 1];
+        order.assign(n, 0);
+        for (int i = lo; i < hi; ++i) order[cnt[R - nrows[i]]++] = i;
+        FirstFit ff(n, R);
+        std::vector<int> last(n, -1);
+        int nb = 0;
+        for (int q = 0; q < n; ++q) {
+            const int it = order[q];
+            int off;
+            const int b = ff.take(nrows[it], &off, R);
+            row0[it] = (tile0 + b) * R + off;
+            last[b] = it;                       // offsets grow with every placement: the latest item is the tile's last
+            nb = std::max(nb, b + 1);
+        }
+        for (int b = 0; b < nb; ++b) ndead[last[b]] = ff.cap(b);
+        tile0 += nb;
+        side_tiles[s + 1] = tile0;
+    }
+    // edge bases: instances in packed row order
+    std::vector<int> by_row(I);
+    for (int i = 0; i < I; ++i) by_row[i] = i;
+    std::sort(by_row.begin(), by_row.end(), [&](int a, int b) { return row0[a] < row0[b]; });
+    long long e = 0;
+    for (int q = 0; q < I; ++q) {
+        ebase[by_row[q]] = (int)e;
+        e += st_nedges[mid[by_row[q]]];
+    }
+    BMP_REQUIRE(e == n_edges && e < (1ll << 31) && (long long)tile0 * R < (1ll << 29));
+    totals[0] = tile0; totals[1] = n_edges; totals[2] = n_real; totals[3] = max_rows;
+    return 0;
+}
+
+// Co-attention metadata of a two-sided batch of B pairs (instances [0, B) are side 1, [B, 2B) side 2), from the plan
+// table: what bmp/coattention.py:pair_rows computes with numpy.  meta (8 * B int32 entries, 8-byte aligned):
+//   coff[B] as int64 (= 2B int32) | r1[B] | n1[B] | r2[B] (relative to side 2's first row) | n2[B] |
+//   order[B] (size classes ascending, stable) | order_f[B] (size classes descending, stable).
+// counts [4]: pairs per size class ceil(max(n1, n2) / 32) - 1;  ctotal: floats of all C blocks
+// (C [n2 x n1] and the softmax statistics of its rows and columns, bmp_coattn_nie_fwd).
+extern "C" int bmp_collate_pair_meta(const int* tab, int I, int B, int side1_tiles, int R, int* meta, int* counts,
+                                     long long* ctotal) {
+    BMP_REQUIRE(tab && meta && counts && ctotal && B >= 1 && I == 2 * B);
+    const int* row0 = tab; const int* nrows = tab + I;
+    long long* coff = reinterpret_cast<long long*>(meta);
+    int* r1 = meta + 2 * (size_t)B; int* n1 = r1 + B; int* r2 = n1 + B; int* n2 = r2 + B; int* ord = n2 + B; int* ordf = ord + B;
+    long long c = 0;
+    int cnt[5] = {0, 0, 0, 0, 0};
+    std::vector<int> cls(B);
+    for (int p = 0; p < B; ++p) {
+        const int a = nrows[p], b = nrows[B + p];
+        coff[p] = c;
+        c += (long long)a * b + 2ll * (a + b);
+        r1[p] = row0[p]; n1[p] = a;
+        r2[p] = row0[B + p] - side1_tiles * R; n2[p] = b;
+        const int k = (std::max(a, b) + 31) / 32 - 1;
+        BMP_REQUIRE(k >= 0 && k < 4);
+        cls[p] = k; ++cnt[k];
+    }
+    int start[4], startf[4];
+    start[0] = 0;
+    for (int k = 1; k < 4; ++k) start[k] = start[k - 1] + cnt[k - 1];
+    startf[3] = 0;
+    for (int k = 2; k >= 0; --k) startf[k] = startf[k + 1] + cnt[k + 1];
+    for (int p = 0; p < B; ++p) { ord[start[cls[p]]++] = p; ordf[startf[cls[p]]++] = p; }
+    for (int k = 0; k < 4; ++k) counts[k] = cnt[k];
+    *ctotal = c;
+    return 0;
+}
+
+// One wavefront per molecule instance (4 per workgroup).  st_rowoff [M + 1] / st_eoff [M + 1]: row / entry ranges of the
+// store's molecules; st_atom: atom ids (0 at the virtual pad row); st_rend / st_rendT: per store row, END of the row's
+// entries inside the molecule (local); st_col / st_colT: local_row << 2 | bond type.
+__global__ __launch_bounds__(256) void k_collate_emit(const int* __restrict__ tab, int I, const int* __restrict__ st_rowoff,
+                                                      const int* __restrict__ st_eoff, const int* __restrict__ st_atom,
+                                                      const int* __restrict__ st_rend, const int* __restrict__ st_rendT,
+                                                      const int* __restrict__ st_col, const int* __restrict__ st_colT,
+                                                      int* __restrict__ atom_id, float* __restrict__ row_w, int* __restrict__ row_mol,
+                                                      int* __restrict__ csr_ptr, int* __restrict__ csr_col, float* __restrict__ csr_val,
+                                                      int* __restrict__ csrT_ptr, int* __restrict__ csrT_col,
+                                                      float* __restrict__ csrT_val) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= I) return;
+    const int row0 = tab[i], nrows = tab[I + i], mid = tab[2 * (size_t)I + i], ebase = tab[3 * (size_t)I + i];
+    const int padw = tab[4 * (size_t)I + i], ndead = tab[5 * (size_t)I + i];
+    const int ro = st_rowoff[mid], eo = st_eoff[mid], ne = st_eoff[mid + 1] - eo;
+    for (int l = lane; l < nrows; l += 64) {
+        const int r = row0 + l;
+        atom_id[r] = st_atom[ro + l];
+        row_w[r] = (l == nrows - 1) ? (float)padw : 1.0f;
+        row_mol[r] = i;
+        csr_ptr[r + 1] = ebase + st_rend[ro + l];
+        csrT_ptr[r + 1] = ebase + st_rendT[ro + l];
+    }
+    for (int k = lane; k < ndead; k += 64) {
+        const int r = row0 + nrows + k;
+        atom_id[r] = 0;
+        row_w[r] = 0.f;
+        row_mol[r] = -1;
+        csr_ptr[r + 1] = ebase + ne;
+        csrT_ptr[r + 1] = ebase + ne;
+    }
+    const int shift = row0 << 2;
+    for (int e = lane; e < ne; e += 64) {
+        csr_col[ebase + e] = st_col[eo + e] + shift;
+        csr_val[ebase + e] = 1.0f;
+        csrT_col[ebase + e] = st_colT[eo + e] + shift;
+        csrT_val[ebase + e] = 1.0f;
+    }
+    if (row0 == 0 && lane == 0) { csr_ptr[0] = 0; csrT_ptr[0] = 0; }
+}
+
+// tab: the plan table of bmp_collate_plan, on the device.  Output arrays as in bmp/packed.py:PackedMolBatch
+// (N = n_tiles * R rows; csr_ptr / csrT_ptr hold N + 1 entries; col / val hold n_edges).
+extern "C" int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, const int* st_eoff, const int* st_atom,
+                                const int* st_rend, const int* st_rendT, const int* st_col, const int* st_colT, int* atom_id,
+                                float* row_w, int* row_mol, int* csr_ptr, int* csr_col, float* csr_val, int* csrT_ptr,
+                                int* csrT_col, float* csrT_val, hipStream_t st) {
+    BMP_REQUIRE(tab && st_rowoff && st_eoff && st_atom && st_rend && st_rendT && st_col && st_colT && atom_id && row_w &&
+                row_mol && csr_ptr && csr_col && csr_val && csrT_ptr && csrT_col && csrT_val && I >= 1);
+    hipLaunchKernelGGL(k_collate_emit, dim3((I + 3) / 4), dim3(256), 0, st, tab, I, st_rowoff, st_eoff, st_atom, st_rend,
+                       st_rendT, st_col, st_colT, atom_id, row_w, row_mol, csr_ptr, csr_col, csr_val, csrT_ptr, csrT_col,
+                       csrT_val);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}

@@ -860,7 +860,7 @@ static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) 
     const double rows = (double)n_tiles * FZ_R;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
-                      4.0 * rows * D * (bwd ? 13.0 : 6.0), st);
+                      4.0 * rows * D * (bwd ? 13.0 : 6.0), st, FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER);
     if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
@@ -938,7 +938,8 @@ static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
         attr_set[bwd ? 1 : 0] = true;
     }
     const double rows = (double)n_tiles * FZ_R;
-    BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * 5.0 * D * D, 4.0 * rows * D * (bwd ? 8.0 : 2.0), st);
+    BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * 5.0 * D * D, 4.0 * rows * D * (bwd ? 8.0 : 2.0), st,
+                      BMP_KID_RELGCN);
     if (bwd) hipLaunchKernelGGL((k_relgcn_layer_bwd<D>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     else hipLaunchKernelGGL((k_relgcn_layer_fwd<D>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
@@ -1004,7 +1005,8 @@ static int ro_launch(const ROArgs& a, int n_tiles, hipStream_t st) {
         attr_set = true;
     }
     const double rows = (double)n_tiles * FZ_R;
-    BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * (HAS0 ? 2.0 : 1.0) * D * 2.0 * D, 4.0 * rows * D * (HAS0 ? 4.0 : 3.0), st);
+    BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * (HAS0 ? 2.0 : 1.0) * D * 2.0 * D, 4.0 * rows * D * (HAS0 ? 4.0 : 3.0), st,
+                      BMP_KID_READOUT_TILE);
     hipLaunchKernelGGL((k_readout_tile_fwd<D, HAS0>), dim3(n_tiles), dim3(512), ro_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;

@@ -398,7 +398,7 @@ int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStre
         flops += 2.0 * rows * ksum * a[p].Nout; bytes += 4.0 * rows * (ksum + a[p].Nout);
     }
     for (int p = n; p <= 3; ++p) m.tx0[p] = tiles;
-    BmpProfScope prof(BMP_KCLS_ROWGEMM, flops, bytes, st);
+    BmpProfScope prof(BMP_KCLS_ROWGEMM, flops, bytes, st, BMP_KID_ROWGEMM_MULTI);
     hipLaunchKernelGGL(k_rowgemm_multi, dim3(2 * tiles, nymax), dim3(256), 0, st, m);
     BMP_LAUNCH_CHECK();
     return 0;
@@ -701,7 +701,10 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
         WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws, a.onehot};
         dim3 grid((a.K + 127) / 128, (a.Nn + 127) / 128, S);
         {
-            BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st);
+            // the one-hot form multiplies by an indicator: a scatter-add done as a GEMM, no algorithmic flops
+            BmpProfScope prof(BMP_KCLS_WGRAD, a.onehot ? 0.0 : 2.0 * a.N * (double)a.K * a.Nn,
+                              4.0 * a.N * ((a.onehot ? 1.0 : (double)a.K) + a.Nn), st,
+                              a.onehot ? BMP_KID_WGRAD_ONEHOT : (a.X2 ? BMP_KID_WGRAD_X2 : BMP_KID_WGRAD));
             if (a.X2) hipLaunchKernelGGL((k_wgrad_lds<true>), grid, dim3(256), 0, st, k, want_cs);
             else hipLaunchKernelGGL((k_wgrad_lds<false>), grid, dim3(256), 0, st, k, want_cs);
         }
@@ -721,7 +724,7 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
     WGKArgs k{a.X, a.X2, a.ldx, a.ldx2, a.dY, a.ldy, a.K, a.Nn, a.N, rps, ws, nullptr};
     dim3 grid((a.K + 64 * mb - 1) / (64 * mb), (a.Nn + 64 * nb - 1) / (64 * nb), S);
     {
-    BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st);
+    BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * a.N * (double)a.K * a.Nn, 4.0 * a.N * ((double)a.K + a.Nn), st, BMP_KID_WGRAD_DIRECT);
     if (mb == 2 && nb == 2) hipLaunchKernelGGL((k_wgrad<2, 2>), grid, dim3(256), 0, st, k);
     else if (mb == 2) hipLaunchKernelGGL((k_wgrad<2, 1>), grid, dim3(256), 0, st, k);
     else if (nb == 2) hipLaunchKernelGGL((k_wgrad<1, 2>), grid, dim3(256), 0, st, k);
@@ -783,7 +786,7 @@ int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
         bytes += 4.0 * a[p].N * ((double)a[p].K + a[p].Nn);
     }
     {
-        BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st);
+        BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, BMP_KID_WGRAD_MULTI);
         hipLaunchKernelGGL(k_wgrad_lds_multi, dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
     }
     BMP_LAUNCH_CHECK();

@@ -89,9 +89,14 @@ int bmp_launch_gather_bwd(const float* dagg, int N, int d, const int* ptrT, cons
 // class is bracketed by two events on the launch stream.
 // ---------------------------------------------------------------------------------------------
 enum { BMP_KCLS_ROWGEMM = 1, BMP_KCLS_WGRAD = 2, BMP_KCLS_GATHER = 3, BMP_KCLS_COATTN = 4, BMP_KCLS_STEP_FWD = 5,
-       BMP_KCLS_STEP_BWD = 6 };
+       BMP_KCLS_STEP_BWD = 6, BMP_KCLS_ALL = -1 };
+// kernel ids inside a class (bmp_prof_collect reports per kernel: key = class * 16 + id)
+enum { BMP_KID_ROWGEMM = 0, BMP_KID_ROWGEMM_MULTI = 1, BMP_KID_READOUT_TILE = 2,
+       BMP_KID_WGRAD = 0, BMP_KID_WGRAD_X2 = 1, BMP_KID_WGRAD_ONEHOT = 2, BMP_KID_WGRAD_DIRECT = 3, BMP_KID_WGRAD_MULTI = 4,
+       BMP_KID_COATTN_FWD = 0, BMP_KID_COATTN_BWD = 1,
+       BMP_KID_GGNN_LATER = 0, BMP_KID_GGNN_FIRST = 1, BMP_KID_RELGCN = 2 };
 struct BmpProfScope {
-    BmpProfScope(int kclass, double flops, double bytes, hipStream_t st);
+    BmpProfScope(int kclass, double flops, double bytes, hipStream_t st, int kid = 0);
     ~BmpProfScope();
     int slot;
     hipStream_t st;

@@ -3,16 +3,16 @@
 #include "bmp_kernels.h"
 
 namespace {
-struct Rec { hipEvent_t a, b; double flops, bytes; };
+struct Rec { hipEvent_t a, b; double flops, bytes; int key; };
 int g_cls = 0;
 std::vector<Rec> g_recs;
 }  // namespace
 
-BmpProfScope::BmpProfScope(int kclass, double flops, double bytes, hipStream_t s) : slot(-1), st(s) {
-    if (g_cls == 0 || kclass != g_cls) return;
+BmpProfScope::BmpProfScope(int kclass, double flops, double bytes, hipStream_t s, int kid) : slot(-1), st(s) {
+    if (g_cls == 0 || (kclass != g_cls && g_cls != BMP_KCLS_ALL)) return;
     Rec r;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    r.flops = flops; r.bytes = bytes;
+    r.flops = flops; r.bytes = bytes; r.key = kclass * 16 + kid;
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
@@ -44,5 +44,24 @@ extern "C" int bmp_prof_stop(double* out) {
     g_recs.clear();
     g_cls = 0;
     out[0] = ms; out[1] = fl; out[2] = by;
+    return n;
+}
+
+// As bmp_prof_stop, per kernel: waits for the recorded launches and aggregates them by key = class * 16 + kernel id
+// (bmp_kernels.h) into key / count / ms / flops / bytes [cap]; returns the number of distinct keys (<= cap).
+extern "C" int bmp_prof_collect(int* key, int* count, double* ms, double* flops, double* bytes, int cap) {
+    int n = 0;
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            int k = 0;
+            while (k < n && key[k] != r.key) ++k;
+            if (k == n && n < cap) { key[n] = r.key; count[n] = 0; ms[n] = flops[n] = bytes[n] = 0.0; ++n; }
+            if (k < n) { ++count[k]; ms[k] += t; flops[k] += r.flops; bytes[k] += r.bytes; }
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    g_cls = 0;
     return n;
 }

@@ -39,6 +39,10 @@ int bmp_tile_rows(void);
  * for the launches, returns their count and fills out[0..2] = total ms, executed flops, bytes. */
 int bmp_prof_start(int kclass);
 int bmp_prof_stop(double* out);
+/* kclass -1 arms every class; bmp_prof_collect then reports per kernel: key = class * 16 + kernel id (csrc/bmp_kernels.h),
+ * launches, total ms, executed flops and bytes as the launchers state them, into arrays of `cap` entries; returns the
+ * number of distinct keys. */
+int bmp_prof_collect(int* key, int* count, double* ms, double* flops, double* bytes, int cap);
 
 /* EmbedAtomID lookup -- chainer_chemistry EmbedAtomID used at models/ggnn.py:85,603
  * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:].  bwd accumulates INTO dW [V x d]. */
@@ -206,6 +210,27 @@ int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, 
  * the host packer's order; rowmap [mb x A] = packed row of every dense position, ptr [N + 1] = row pointers. */
 int bmp_dense_count(const float* adj, int mb, int A, int* row_nnz, int* col_nnz, bmp_stream_t stream);
 int bmp_dense_to_csr(const float* adj, int mb, int A, const int* rowmap, const int* ptr, int transposed, int* col, float* val,
+                     bmp_stream_t stream);
+
+/* ---- the per-iteration collate for a drug store resident in HBM (SerialIterator + converter=concat_mols,
+ * train_ddi_modify.py:280,295-296; the batch contract of SURVEY.md 8(a) R0 from index pairs) ----
+ * bmp_collate_plan and bmp_collate_pair_meta are HOST functions (host pointers, no device work, no stream): the size
+ * arithmetic of concat_mols (zero-padding width per batch side) and of the packed layout (first-fit-decreasing tile
+ * placement, entry bases, dead rows), and the co-attention's per-pair metadata.  st_nrows / st_nedges [n_store]: rows
+ * (real atoms + 1) and directed bonds of every molecule of the store; mids: molecule of every instance, the sides of the
+ * batch one after the other (side_ptr [n_sides + 1]); pad_to [n_sides] or NULL.  tab (out, 6 * I int32):
+ * row0 | nrows | mid | ebase | padw | ndead.  side_tiles (out) [n_sides + 1]; totals (out) [4]: n_tiles, n_edges,
+ * n_real_atoms, max rows of an instance.  meta (out, 8 * B int32, 8-byte aligned): coff (int64) | r1 | n1 | r2 | n2 |
+ * order | order_f as bmp_coattn_nie_fwd/_bwd take them; counts [4]; ctotal.
+ * bmp_collate_emit (DEVICE): writes the packed batch of bmp/packed.py from the plan table and the store's arrays
+ * (st_rowoff / st_eoff [M + 1], st_atom, per-row local entry ends st_rend / st_rendT, local entries st_col / st_colT =
+ * local row << 2 | bond type).  Bit-identical to the host packer. */
+int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n_store, const int* mids, const int* side_ptr,
+                     int n_sides, const int* pad_to, int R, int* tab, int* side_tiles, long long* totals);
+int bmp_collate_pair_meta(const int* tab, int I, int B, int side1_tiles, int R, int* meta, int* counts, long long* ctotal);
+int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, const int* st_eoff, const int* st_atom, const int* st_rend,
+                     const int* st_rendT, const int* st_col, const int* st_colT, int* atom_id, float* row_w, int* row_mol,
+                     int* csr_ptr, int* csr_col, float* csr_val, int* csrT_ptr, int* csrT_col, float* csrT_val,
                      bmp_stream_t stream);
 
 /* ---- link predictor tail: MLP (models/mlp.py:20-45: Linear -> relu -> ... -> Linear on [g1 | g2], train_binary.py:98-101)

@@ -1,0 +1,109 @@
+"""The per-iteration collate (train_ddi_modify.py:280,295-296) as index work: bmp_collate_plan / bmp_collate_pair_meta are
+HOST functions of the C ABI, so they run here without a GPU.  Checked bit for bit against the numpy packer
+(bmp.packed.pack_from_store, itself checked against the dense form in test_packed.py): the plan's placement equals
+``_bin_pack``, and the plan + the store's local CSR reproduce every array of the packed batch (the device kernel
+bmp_collate_emit is restated in numpy below; its GPU run is tests/test_gpu_collate.py)."""
+import numpy as np
+import pytest
+import torch
+
+from bmp import packed, synth
+
+
+def emit_numpy(ds: "packed.DeviceMolStore", tab, I, n_tiles, E, R):
+    """What k_collate_emit writes, one instance at a time."""
+    rowoff, eoff, atom, rend, rendT, col, colT = ds.host_arrays
+    N = n_tiles * R
+    out = dict(atom_id=np.full(N, -7, np.int32), row_w=np.full(N, -7, np.float32), row_mol=np.full(N, -7, np.int32),
+               csr_ptr=np.full(N + 1, -7, np.int32), csrT_ptr=np.full(N + 1, -7, np.int32), csr_col=np.full(E, -7, np.int32),
+               csrT_col=np.full(E, -7, np.int32), csr_val=np.full(E, -7, np.float32), csrT_val=np.full(E, -7, np.float32))
+    row0, nrows, mid, ebase, padw, ndead = (tab[k * I:(k + 1) * I] for k in range(6))
+    for i in range(I):
+        ro, eo = rowoff[mid[i]], eoff[mid[i]]
+        ne = eoff[mid[i] + 1] - eo
+        r = row0[i] + np.arange(nrows[i])
+        out["atom_id"][r] = atom[ro:ro + nrows[i]]
+        out["row_w"][r] = 1.0
+        out["row_w"][r[-1]] = padw[i]
+        out["row_mol"][r] = i
+        out["csr_ptr"][r + 1] = ebase[i] + rend[ro:ro + nrows[i]]
+        out["csrT_ptr"][r + 1] = ebase[i] + rendT[ro:ro + nrows[i]]
+        dr = row0[i] + nrows[i] + np.arange(ndead[i])
+        out["atom_id"][dr] = 0; out["row_w"][dr] = 0; out["row_mol"][dr] = -1
+        out["csr_ptr"][dr + 1] = ebase[i] + ne; out["csrT_ptr"][dr + 1] = ebase[i] + ne
+        out["csr_col"][ebase[i]:ebase[i] + ne] = col[eo:eo + ne] + (row0[i] << 2)
+        out["csrT_col"][ebase[i]:ebase[i] + ne] = colT[eo:eo + ne] + (row0[i] << 2)
+        out["csr_val"][ebase[i]:ebase[i] + ne] = 1.0
+        out["csrT_val"][ebase[i]:ebase[i] + ne] = 1.0
+        if row0[i] == 0:
+            out["csr_ptr"][0] = 0; out["csrT_ptr"][0] = 0
+    return out
+
+
+@pytest.mark.parametrize("n_mols,B,seed,pad_to", [(60, 37, 0, None), (544, 1024, 1, None), (30, 8, 2, (70, 64)),
+                                                   (12, 1, 3, None), (300, 256, 4, None)])
+def test_plan_and_emit_equal_host_packer(n_mols, B, seed, pad_to):
+    store = synth.make_store(n_mols, seed=10 + seed, n_lo=1, n_hi=60 if pad_to else 96, n_mean=22)
+    ms = packed.MolStore(store)
+    ds = packed.DeviceMolStore(ms, "cpu")
+    rs = np.random.RandomState(seed)
+    sides = [rs.randint(0, n_mols, B), rs.randint(0, n_mols, B)]
+    ref = packed.pack_from_store(ms, sides, pad_to=pad_to)
+    tab, side_tiles, side_mols, n_tiles, E, n_real, max_rows = packed.collate_plan_host(ds.st_nrows, ds.st_nedges, sides, pad_to=pad_to)
+    I = 2 * B
+    assert (side_tiles, side_mols, n_tiles, E, n_real, max_rows) == (
+        ref.side_tiles, ref.side_mols, ref.n_tiles, ref.n_edges, ref.n_real_atoms, ref.max_rows_per_mol)
+    assert np.array_equal(tab[:I], ref.mol_row0.numpy()) and np.array_equal(tab[I:2 * I], ref.mol_nrows.numpy())
+    got = emit_numpy(ds, tab, I, n_tiles, E, ref.R)
+    for k, v in got.items():
+        assert np.array_equal(v, getattr(ref, k).numpy()), k          # every element written, every element equal
+
+
+def test_plan_placement_is_first_fit_decreasing():
+    rs = np.random.RandomState(5)
+    for trial in range(20):
+        n = rs.randint(1, 400)
+        sizes = rs.randint(1, 129, size=n).astype(np.int64)
+        bins, offs, nb = packed._bin_pack(sizes, 128)
+        nedges = np.zeros(n, np.int32)
+        tab, side_tiles, _sm, n_tiles, *_ = packed.collate_plan_host(sizes.astype(np.int32), nedges, [np.arange(n)])
+        assert n_tiles == nb and np.array_equal(tab[:n], bins * 128 + offs)
+        # dead rows: exactly the rows no instance covers
+        cover = np.zeros(nb * 128, np.int32)
+        for i in range(n):
+            cover[tab[i]:tab[i] + sizes[i] + tab[5 * n + i]] += 1
+        assert (cover == 1).all()
+
+
+def test_pair_meta_equals_numpy_form():
+    from bmp import _lib
+    from bmp.coattention import _cbuf_floats, _size_classes
+    store = synth.make_store(200, seed=3, n_lo=1, n_hi=120, n_mean=30)
+    ms = packed.MolStore(store)
+    ds = packed.DeviceMolStore(ms, "cpu")
+    rs = np.random.RandomState(1)
+    B = 333
+    sides = [rs.randint(0, 200, B), rs.randint(0, 200, B)]
+    tab, side_tiles, *_ = packed.collate_plan_host(ds.st_nrows, ds.st_nedges, sides)
+    meta = np.zeros(8 * B, np.int32); cnt = np.zeros(4, np.int32); ct = np.zeros(1, np.int64)
+    _lib.check(_lib.lib().bmp_collate_pair_meta(packed._i32p(tab), 2 * B, B, side_tiles[1], 128, packed._i32p(meta),
+                                                packed._i32p(cnt), packed._i32p(ct)), "pair_meta")
+    nr = tab[2 * B:4 * B].astype(np.int64)
+    nr1, nr2 = nr[:B], nr[B:]
+    coff = np.concatenate(([0], np.cumsum(_cbuf_floats(nr1, nr2))))
+    order, counts, order_f, counts_f = _size_classes(nr1, nr2, "cpu")
+    assert np.array_equal(meta[:2 * B].view(np.int64), coff[:-1]) and ct[0] == coff[-1]
+    assert np.array_equal(meta[2 * B:3 * B], tab[:B]) and np.array_equal(meta[3 * B:4 * B], nr1)
+    assert np.array_equal(meta[4 * B:5 * B], tab[B:2 * B] - side_tiles[1] * 128) and np.array_equal(meta[5 * B:6 * B], nr2)
+    assert np.array_equal(meta[6 * B:7 * B], order.numpy()) and np.array_equal(meta[7 * B:], order_f.numpy())
+    assert list(cnt) == counts
+
+
+def test_plan_rejects_bad_input():
+    nrows = np.array([5, 200], np.int32); ne = np.zeros(2, np.int32)
+    with pytest.raises(ValueError):
+        packed.collate_plan_host(nrows, ne, [np.array([1])])              # does not fit a tile
+    with pytest.raises(ValueError):
+        packed.collate_plan_host(nrows, ne, [np.array([2])])              # molecule index out of range
+    with pytest.raises(ValueError):
+        packed.collate_plan_host(nrows, ne, [np.array([0])], pad_to=[2])  # pad_to below the side's largest molecule
