@@ -29,6 +29,7 @@ form in tests/test_packed.py.
 """
 from __future__ import annotations
 
+import time as _time
 from ctypes import c_void_p as _c_void_p
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -472,6 +473,7 @@ class DeviceMolStore:
         colT, rendT = local_csr(store.e_src, store.e_dst)
         host = [rowoff.astype(np.int32), eoff.astype(np.int32), store.atom_flat.astype(np.int32), rend, rendT, col, colT]
         self.host_arrays = host
+        self.plan_seconds, self.plan_calls = 0.0, 0
         if self.device.type == "cuda":
             buf = torch.from_numpy(np.concatenate(host)).to(self.device)
             self.dev, o = [], 0
@@ -519,8 +521,9 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
     n_meta = 8 * B if paired else 0
     lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
     n_lab = 0 if lab is None else lab.size
-    st = dstore._staging(n_tab + n_meta + n_lab)
+    st = dstore._staging(n_tab + n_meta + n_lab)          # may wait for the copy that last used this buffer
     st_np = st.numpy()
+    t_plan = _time.perf_counter()
     tab, side_tiles, side_mols, n_tiles, E, n_real, max_rows = collate_plan_host(
         dstore.st_nrows, dstore.st_nedges, sides, R, pad_to, tab=st_np[:6 * I])
     counts, ctotal = None, 0
@@ -531,17 +534,20 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
         counts, ctotal = [int(c) for c in cnt], int(ct[0])
     if lab is not None:
         st_np[n_tab + n_meta:n_tab + n_meta + n_lab] = lab
+    dstore.plan_seconds += _time.perf_counter() - t_plan          # the host's share of the collate (size arithmetic)
+    dstore.plan_calls += 1
     n_up = n_tab + n_meta + n_lab
     up = torch.empty(n_up, dtype=torch.int32, device=dev)
     up.copy_(st[:n_up], non_blocking=True)
     dstore._staged()
     N = n_tiles * R
-    ibuf = torch.empty(3 * N + 2 + 2 * E, dtype=torch.int32, device=dev)
+    ibuf = torch.empty(4 * N + 2 + 2 * E, dtype=torch.int32, device=dev)
     fbuf = torch.empty(N + 2 * E, dtype=torch.float32, device=dev)
     atom_id, csr_ptr, csr_col = ibuf[:N], ibuf[N:2 * N + 1], ibuf[2 * N + 1:2 * N + 1 + E]
     o = 2 * N + 1 + E
     csrT_ptr, csrT_col, row_mol = ibuf[o:o + N + 1], ibuf[o + N + 1:o + N + 1 + E], ibuf[o + N + 1 + E:o + 2 * N + 1 + E]
     row_w, csr_val, csrT_val = fbuf[:N], fbuf[N:N + E], fbuf[N + E:]
+    assert row_mol.numel() == N and csrT_val.numel() == E and csrT_ptr.numel() == N + 1
     d = dstore.dev
     check(L.bmp_collate_emit(ptr(up), I, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(d[5]), ptr(d[6]),
                              ptr(atom_id), ptr(row_w), ptr(row_mol), ptr(csr_ptr), ptr(csr_col), ptr(csr_val), ptr(csrT_ptr),
