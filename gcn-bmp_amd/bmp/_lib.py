@@ -23,7 +23,7 @@ SIGNATURES = {
     "bmp_prof_start": (_I, [_I]),
     "bmp_prof_stop": (_I, [_P]),
     "bmp_prof_collect": (_I, [_P, _P, _P, _P, _P, _I]),
-    "bmp_embed_fwd": (_I, [_P, _P, _I, _I, _P, _P]),
+    "bmp_embed_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "bmp_embed_bwd_ws_floats": (_Z, [_I, _I, _I]),
     "bmp_embed_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, _P]),
     "bmp_msg_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),

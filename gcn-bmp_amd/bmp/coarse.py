@@ -204,8 +204,8 @@ class _Side:
 def _sides(atoms_1, atoms_2):
     """(side over which module 'focus 1' attends, side for focus 2, per-molecule permutation to the OTHER molecule).
     One two-sided batch: a single _Side with other[m] = partner molecule; two batches: one _Side each."""
-    if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
-        raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+    from .ggnn import as_packed_atoms
+    atoms_1, atoms_2 = as_packed_atoms(atoms_1), as_packed_atoms(atoms_2)          # dense (mb, N, hid) arrays accepted
     if atoms_1.pb is atoms_2.pb and len(atoms_1.pb.side_mols) == 3:
         return _Side(atoms_1), None
     return _Side(atoms_1), _Side(atoms_2)

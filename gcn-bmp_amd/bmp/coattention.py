@@ -18,7 +18,7 @@ from torch.autograd import Function
 from . import _lib
 from ._lib import check, ptr, stream
 from .functional import ACT, _ws
-from .ggnn import Linear, PackedAtoms
+from .ggnn import Linear, PackedAtoms, as_packed_atoms
 
 
 class Bilinear(nn.Module):
@@ -283,8 +283,7 @@ class NieFineCoattention(_FinePlanMixin, nn.Module):
         return WbT, ZW1T, ZW2T, zb, self.attention_layer_1.W[0], self.attention_layer_2.W[0], E.b
 
     def forward(self, atoms_1, g_1, atoms_2, g_2, **_) -> Tuple[torch.Tensor, torch.Tensor]:
-        if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
-            raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        atoms_1, atoms_2 = as_packed_atoms(atoms_1), as_packed_atoms(atoms_2)      # dense (mb, N, hid) arrays: :335-341
         fast = getattr(self, "_fast", None)
         if fast is not None:
             return self._forward_fast(atoms_1, atoms_2, fast, 0)
@@ -349,8 +348,7 @@ class _DeepNie(NieFineCoattention):
         return WbT, ZW[0], ZW[1], torch.stack(zb), self.attention_layer_1.W[0], self.attention_layer_2.W[0], E.b
 
     def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
-        if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
-            raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        atoms_1, atoms_2 = as_packed_atoms(atoms_1), as_packed_atoms(atoms_2)      # dense (mb, N, hid) arrays: :335-341
         X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
         WbT, ZW1T, ZW2T, zb, wa1, wa2, cb = self._kernel_weights()
         return NieCoattnFn.apply(X1, X2, WbT, ZW1T, ZW2T, zb, wa1, wa2, cb, w1, w2, meta, self.hidden_dim,
@@ -432,8 +430,7 @@ class PoolingFineCoattention(_FinePlanMixin, nn.Module):
         self.activation = activation
 
     def forward(self, atoms_1, g_1, atoms_2, g_2, **_):
-        if not isinstance(atoms_1, PackedAtoms) or not isinstance(atoms_2, PackedAtoms):
-            raise NotImplementedError("co-attention expects the PackedAtoms returned by get_atom_array()")
+        atoms_1, atoms_2 = as_packed_atoms(atoms_1), as_packed_atoms(atoms_2)      # dense (mb, N, hid) arrays: :335-341
         fast = getattr(self, "_fast", None)
         if fast is not None:
             return self._forward_fast(atoms_1, atoms_2, fast, 1)

@@ -67,6 +67,9 @@ class FlatAdam:
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise ValueError("module has no parameters")
+        if any(isinstance(p, nn.UninitializedParameter) for p in params):
+            raise ValueError("the module still has a lazily sized Linear (MLP / SymMLP / HolE built without in_dim / fp_dim): "
+                             "call it once, or build it inside GraphConvPredictorForPair, before FlatAdam flattens the parameters")
         dev = params[0].device
         total = sum(p.numel() for p in params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)

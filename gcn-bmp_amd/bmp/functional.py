@@ -42,7 +42,7 @@ class EmbedFn(Function):
         V, d = W.shape
         N = ids.numel()
         out = torch.empty(N, d, dtype=torch.float32, device=W.device)
-        check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, ptr(out), stream()), "bmp_embed_fwd")
+        check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, V, ptr(out), stream()), "bmp_embed_fwd")
         ctx.save_for_backward(ids)
         ctx.V = V
         return out
@@ -240,6 +240,9 @@ class GGNNStepFn(Function):
             st["seen"] += 1
             if st["seen"] < cache[("n",) + grp[1:]]:
                 return dh, None, None, None, None, None, None, None, None
+            # the group's last step of THIS backward: a later backward over the same graph (retain_graph, a second
+            # autograd.grad) starts a fresh accumulation in fresh buffers instead of adding to these sums
+            st["seen"], st["buf"] = 0, None
         dWT = o1[:, :4 * d].reshape(d, 4, d).permute(1, 0, 2).reshape(4 * d, d)      # [k][e*d+c] -> [e*d+k][c]
         dbE = cs[:4 * d].reshape(4, d)
         dAT = torch.cat((o1[:, 4 * d:], o2), dim=0)
@@ -372,12 +375,20 @@ class LinearRowsFn(Function):
 # autograd only carries the row tensors.  ``tape`` is a dummy 1-element tensor that requires grad: it makes
 # autograd run the backward of ops whose only differentiable input would have been a weight.
 # ---------------------------------------------------------------------------------------------------------
+def _register(state, key) -> None:
+    """Forward side of _first_write: counts the ops of this step that will write the gradient buffer ``key``."""
+    state[("nf", key)] = state.get(("nf", key), 0) + 1
+
+
 def _first_write(state, key) -> bool:
-    """True the first time a gradient buffer of the plan is written in this backward (the kernel overwrites it);
-    later writers (the encoder is called once per side in the reference's four-array form) go through a temporary."""
-    first = not state.get(key)
-    state[key] = True
-    return first
+    """True for the first writer of a gradient buffer of the plan in a backward pass (the kernel overwrites the buffer);
+    later writers of the same pass (tied steps; the encoder called once per side in the reference's four-array form)
+    accumulate.  Writers are counted against the forward's registrations, so a SECOND backward over the same graph
+    (retain_graph) overwrites again instead of adding to the first pass's sums."""
+    nf = max(state.get(("nf", key), 1), 1)
+    nb = state.get(("nb", key), 0)
+    state[("nb", key)] = nb + 1
+    return nb % nf == 0
 
 
 class PEmbedFn(Function):
@@ -387,8 +398,9 @@ class PEmbedFn(Function):
         V, d = W.shape
         N = ids.numel()
         out = torch.empty(N, d, dtype=torch.float32, device=W.device)
-        check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, ptr(out), stream()), "bmp_embed_fwd")
+        check(L.bmp_embed_fwd(ptr(ids), ptr(W), N, d, V, ptr(out), stream()), "bmp_embed_fwd")
         ctx.ids, ctx.dW, ctx.V, ctx.state = ids, dW, V, state
+        _register(state, "embed.dW")
         return out
 
     @staticmethod
@@ -423,6 +435,7 @@ class PStepFn(Function):
                                   ptr(c), ptr(hout), stream()), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
+        _register(state, gkey)
         return hout
 
     @staticmethod
@@ -437,12 +450,11 @@ class PStepFn(Function):
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
                                   ptr(dh), ptr(gda), stream()), "bmp_ggnn_step_bwd")
-        acc = 1 if ctx.state.get(ctx.gkey) else 0
+        acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
         nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
         ws = _ws(nws, h.device)
         check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(G["o1"]), ptr(G["o2"]),
                                     ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
-        ctx.state[ctx.gkey] = True
         return dh, None, None, None, None, None, None
 
 
@@ -457,6 +469,7 @@ class PReadoutFn(Function):
         N, d = h.shape
         d0 = 0 if h0 is None else h0.shape[1]
         ctx.state = state
+        _register(state, "ro")
         WT = W["WT"]
         o = WT.shape[1] // 2
         ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o)
@@ -508,6 +521,7 @@ class PMsgFn(Function):
                             d_out, stream()), "bmp_msg_fwd")
         ctx.save_for_backward(x, agg, wdeg, out)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
+        _register(state, gkey)
         return out
 
     @staticmethod
@@ -598,6 +612,7 @@ class PRelLayerFn(Function):
         out, wdeg = _rel_fwd(x, pb, W["WTp"], W["bE"], W["WsTp"], W["bs"], act)
         ctx.save_for_backward(x, out, wdeg)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
+        _register(state, gkey)
         return out
 
     @staticmethod

@@ -30,11 +30,27 @@ class Linear(nn.Module):
     """Parameter holder with Chainer's Linear attribute names (W [out x in], b [out]) and
     default initialisers (W ~ LeCunNormal, b = 0)."""
 
-    def __init__(self, in_size: int, out_size: int, nobias: bool = False):
+    def __init__(self, in_size: Optional[int], out_size: int, nobias: bool = False):
+        """``in_size=None`` is Chainer's ``Linear(None, out)``: W is created at the first call that shows the input
+        width (models/mlp.py:34-37), here by ``materialize``."""
         super().__init__()
-        self.W = nn.Parameter(torch.randn(out_size, in_size) / math.sqrt(in_size))
+        if in_size is None:
+            self.W = nn.UninitializedParameter()
+        else:
+            self.W = nn.Parameter(torch.randn(out_size, in_size) / math.sqrt(in_size))
         self.b = None if nobias else nn.Parameter(torch.zeros(out_size))
         self.in_size, self.out_size = in_size, out_size
+
+    def materialize(self, in_size: int) -> None:
+        if self.in_size is not None:
+            if self.in_size != in_size:
+                raise ValueError(f"Linear was built for {self.in_size} input features, got {in_size}")
+            return
+        dev = self.b.device if self.b is not None else None
+        self.W.materialize((self.out_size, in_size), device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            self.W.copy_(torch.randn(self.out_size, in_size) / math.sqrt(in_size))        # LeCunNormal, as Chainer's Linear
+        self.in_size = in_size
 
 
 class EmbedID(nn.Module):
@@ -90,6 +106,85 @@ class PackedAtoms:
         return self.pb.to_dense(self.rows, self.side if side is None else side)
 
 
+_DENSE_PB_CACHE: dict = {}
+
+
+def packed_atoms_from_dense(x: torch.Tensor) -> PackedAtoms:
+    """The reference hands the co-attention dense atom arrays (mb, N, hidden) (nie_coattention.py:335-341) and masks
+    nothing, so every position is an atom of weight 1: lay them out as packed rows (floor(128 / N) molecules per tile,
+    no bonds, no virtual pad row) and let the pair kernels run unchanged.  Differentiable in ``x``."""
+    from . import _lib
+    if x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError("dense atom arrays must be float32 CUDA tensors of shape (mb, N, hidden_dim)")
+    mb, N, d = x.shape
+    R = _lib.lib().bmp_tile_rows()
+    if N < 1 or N > R:
+        raise ValueError(f"a molecule of {N} positions does not fit a tile of {R} rows")
+    key = (mb, N, x.device)
+    if key not in _DENSE_PB_CACHE:
+        per = R // N
+        n_tiles = (mb + per - 1) // per
+        b = np.arange(mb)
+        row0 = (b // per) * R + (b % per) * N
+        idx = (row0[:, None] + np.arange(N)[None, :]).reshape(-1)
+        n_rows = n_tiles * R
+        row_w = np.zeros(n_rows, np.float32); row_w[idx] = 1.0
+        row_mol = np.full(n_rows, -1, np.int32); row_mol[idx] = np.repeat(b, N)
+        dev = x.device
+        zi = torch.zeros(n_rows + 1, dtype=torch.int32, device=dev)
+        ze = torch.zeros(4, dtype=torch.int32, device=dev)
+        pb = PackedMolBatch(
+            R=R, n_tiles=n_tiles, n_mols=mb, atom_id=zi[:n_rows], row_w=torch.from_numpy(row_w).to(dev), csr_ptr=zi, csr_col=ze[:0],
+            csr_val=ze[:0].float(), csrT_ptr=zi, csrT_col=ze[:0], csrT_val=ze[:0].float(),
+            mol_row0=torch.from_numpy(row0.astype(np.int32)).to(dev), mol_nrows=torch.full((mb,), N, dtype=torch.int32, device=dev),
+            side_tiles=(0, n_tiles), side_mols=(0, mb), n_real_atoms=mb * N, n_edges=0, max_rows_per_mol=N,
+            mol_nrows_host=np.full(mb, N, np.int64), row_mol=torch.from_numpy(row_mol).to(dev))
+        pb.dense_map = torch.from_numpy(idx.reshape(mb, N)).to(dev)
+        pb.dense_maps = [pb.dense_map]
+        if len(_DENSE_PB_CACHE) >= 4:                # the two sides of a pair batch (+ one more batch shape) stay cached
+            _DENSE_PB_CACHE.clear()
+        _DENSE_PB_CACHE[key] = pb
+    pb = _DENSE_PB_CACHE[key]
+    rows = x.new_zeros(pb.n_rows, d).index_copy(0, pb.dense_map.reshape(-1), x.reshape(mb * N, d))
+    return PackedAtoms(rows, pb, 0)
+
+
+def as_packed_atoms(atoms) -> PackedAtoms:
+    """What a co-attention module accepts in its ``atoms_k`` slots: the PackedAtoms of ``get_atom_array()`` or the
+    reference's dense (mb, N, hidden_dim) array."""
+    if isinstance(atoms, PackedAtoms):
+        return atoms
+    if isinstance(atoms, torch.Tensor):
+        return packed_atoms_from_dense(atoms)
+    raise TypeError("atoms must be the PackedAtoms returned by get_atom_array() or a dense (mb, N, hidden_dim) tensor")
+
+
+def pack_float_atoms(x, adj, device):
+    """Float atom features (mb, A, hidden_dim) bypass the embedding (models/ggnn.py:600-605).  No position can be told
+    apart as padding there, so every position becomes a row of its own (nothing is merged into the virtual pad row,
+    whose weight is then 0); returns the batch and the (n_rows, hidden_dim) row tensor, differentiable in ``x``."""
+    xt = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+    if xt.dim() != 3:
+        raise ValueError("float atom features must have shape (mb, A, hidden_dim)")
+    mb, A, d = xt.shape
+    ones = np.ones((mb, A), dtype=np.int32)
+    if isinstance(adj, torch.Tensor) and adj.is_cuda:
+        from .packed import pack_from_dense_device
+        pb = pack_from_dense_device([ones], [adj.detach().float().contiguous()])
+    else:
+        j = adj.detach().cpu().numpy() if isinstance(adj, torch.Tensor) else np.asarray(adj)
+        pb = pack_from_dense([ones], [j.astype(np.float32)], device=device)
+    xt = xt.to(device=device, dtype=torch.float32)
+    rows = xt.new_zeros(pb.n_rows, d).index_copy(0, pb.dense_maps[0].reshape(-1), xt.reshape(mb * A, d))
+    return pb, rows
+
+
+def _is_float_atoms(atom_array) -> bool:
+    if isinstance(atom_array, torch.Tensor):
+        return atom_array.is_floating_point()
+    return not isinstance(atom_array, PackedMolBatch) and np.asarray(atom_array).dtype.kind == "f"
+
+
 def as_packed(atom_array, adj, device) -> PackedMolBatch:
     """Accept the reference's dense batch (atom_array (mb, A) int32, adj (mb, 4, A, A) float32,
     numpy or torch) or an already packed batch in the first slot."""
@@ -125,8 +220,9 @@ class GGNN(nn.Module):
         for k, v in unsupported.items():
             if v:
                 raise NotImplementedError(f"GGNN option {k}={v!r} is outside the MI355X hot path (SURVEY.md 2.1 #1)")
-        if dropout_rate != 0.0:
-            raise NotImplementedError("dropout_rate != 0 is not supported")
+        if not 0.0 <= dropout_rate < 1.0:
+            raise ValueError("dropout_rate must lie in [0, 1)")
+        self.dropout_rate = dropout_rate        # models/ggnn.py:626-627; see forward()
         if message_function != 'matrix_multiply':
             if message_function == 'edge_network':
                 raise NotImplementedError("message_function='edge_network' is not supported")
@@ -219,11 +315,15 @@ class GGNN(nn.Module):
             out[f"gru_{mode}.b"] = [gk[g + ".cs"][4 * d:] for g in mine]
         return out
 
-    def _forward_fast(self, pb, fast):
+    def _forward_fast(self, pb, fast, h_in=None):
         """The encoder on the plan's prepared weights: embed, fused steps, readout -- no layout work, no weight
         gradients through autograd."""
         P, G, state, tape = fast
-        h = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
+        if h_in is None:
+            pb.check_atom_ids(P["embed.W"].shape[0])
+            h = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
+        else:
+            h = h_in
         h0 = h
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
@@ -239,12 +339,27 @@ class GGNN(nn.Module):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``
         (mb, 4, A, A), or a PackedMolBatch (then ``adj`` is ignored).  Returns (n_mols, out_dim)
         [(n_mols, n_layers*out_dim) with concat_hidden]."""
+        if self.dropout_rate != 0.0 and self.training:
+            # F.dropout after every step (models/ggnn.py:626-627) drops the step OUTPUT while the stateful GRU keeps its
+            # own un-dropped state, so the next step sees x = [dropout(h), m(dropout(h))] next to a different state s: the
+            # kernels here fold the state terms into the h-part (s == h).  Under chainer's train=False (evaluators,
+            # predict) dropout is the identity, which is what model.eval() gives.
+            raise NotImplementedError("dropout_rate != 0 is supported in eval mode only (identity, as chainer's "
+                                      "train=False); training with dropout needs a separate-state GRU kernel")
         dev = self.embed.W.device
-        pb = as_packed(atom_array, adj, dev)
+        h_in = None
+        if _is_float_atoms(atom_array):                                 # :604-605: float features skip the embedding
+            pb, h_in = pack_float_atoms(atom_array, adj, dev)
+            if h_in.shape[1] != self.hidden_dim:
+                raise ValueError(f"float atom features must be hidden_dim={self.hidden_dim} wide, got {h_in.shape[1]}")
+        else:
+            pb = as_packed(atom_array, adj, dev)
         fast = getattr(self, "_fast", None)
         if fast is not None:
-            return self._forward_fast(pb, fast)
-        h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)                 # :603
+            return self._forward_fast(pb, fast, h_in)
+        if h_in is None:
+            pb.check_atom_ids(self.embed.W.shape[0])
+        h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id) if h_in is None else h_in      # :603
         h0 = h                                                          # :612
         later = None
         fused = self.fused and Fn.step_supported(self.hidden_dim)

@@ -74,6 +74,7 @@ def _check_act(activation):
 
 class NTN(nn.Module):
     """models/mlp.py:48-72."""
+    is_link_predictor = True
 
     def __init__(self, left_dim, right_dim, out_dim, ntn_out_dim=8, hidden_dims=(16,), activation=torch.relu):
         super().__init__()
@@ -101,6 +102,7 @@ class BilinearDiag(nn.Module):
 
 class DistMult(nn.Module):
     """models/mlp.py:75-93."""
+    is_link_predictor = True
 
     def __init__(self, left_dim, right_dim, out_dim, dm_out_dim=8, hidden_dims=(16,), activation=torch.relu):
         super().__init__()
@@ -118,34 +120,40 @@ class DistMult(nn.Module):
 
 class SymMLP(nn.Module):
     """models/mlp.py:96-110.  ``fp_dim`` = width of left_x / right_x."""
+    is_link_predictor = True
 
     def __init__(self, out_dim, hidden_dims=(32, 16), activation=torch.relu, fp_dim=None):
         super().__init__()
         _check_act(activation)
-        if fp_dim is None:
-            raise ValueError("SymMLP needs fp_dim (Chainer infers it at the first call; torch cannot)")
-        dims = [2 * fp_dim] + list(hidden_dims)
+        dims = [None if fp_dim is None else 2 * fp_dim] + list(hidden_dims)          # None: lazy, models/mlp.py:99-102
         self.layers = nn.ModuleList([Linear(dims[i], dims[i + 1]) for i in range(len(hidden_dims))])
         self.l_out = Linear(dims[-1], out_dim)
 
+    def materialize_input(self, fp_dim: int) -> None:
+        (self.layers[0] if len(self.layers) else self.l_out).materialize(2 * fp_dim)
+
     def forward(self, left_x, right_x):
+        self.materialize_input(left_x.shape[-1])
         h = PairFeatFn.apply(SYM, 0, left_x, right_x, None, None, None, None)
         return _tail(self.layers, self.l_out, h)
 
 
 class HolE(nn.Module):
     """models/mlp.py:113-151.  ``fp_dim`` = width of left_x / right_x."""
+    is_link_predictor = True
 
     def __init__(self, out_dim, hidden_dims=(32, 16), activation=torch.relu, fp_dim=None):
         super().__init__()
         _check_act(activation)
-        if fp_dim is None:
-            raise ValueError("HolE needs fp_dim (Chainer infers it at the first call; torch cannot)")
-        dims = [fp_dim] + list(hidden_dims)
+        dims = [fp_dim] + list(hidden_dims)                                           # None: lazy, models/mlp.py:116-119
         self.layers = nn.ModuleList([Linear(dims[i], dims[i + 1]) for i in range(len(hidden_dims))])
         self.l_out = Linear(dims[-1], out_dim)
 
+    def materialize_input(self, fp_dim: int) -> None:
+        (self.layers[0] if len(self.layers) else self.l_out).materialize(fp_dim)
+
     def forward(self, left_x, right_x):
+        self.materialize_input(left_x.shape[-1])
         return _tail(self.layers, self.l_out, self.circular_correlation(left_x, right_x))
 
     def circular_correlation(self, left_x, right_x):

@@ -115,23 +115,31 @@ def sigmoid_cross_entropy(y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
 
 
 class MLP(nn.Module):
+    is_link_predictor = True
+
     def __init__(self, out_dim, hidden_dims=(32, 16), activation=torch.relu, in_dim=None):
-        """``in_dim`` replaces Chainer's lazy ``Linear(None, ...)`` shape inference."""
+        """models/mlp.py:32-38.  ``in_dim=None`` (the reference's call form, train_ddi_modify.py:136) leaves the first
+        layer's input width open like Chainer's ``Linear(None, ...)``: it is fixed by ``materialize_input`` -- called by
+        GraphConvPredictorForPair from the encoder's / co-attention's out_dim, or at the first forward."""
         super().__init__()
-        if in_dim is None:
-            raise ValueError("MLP needs in_dim (Chainer infers it at the first call; torch cannot)")
         dims = [in_dim] + list(hidden_dims)
         self.layers = nn.ModuleList([Linear(dims[i], dims[i + 1]) for i in range(len(hidden_dims))])
         self.l_out = Linear(dims[-1], out_dim)
         self.activation = activation
         self.in_dim, self.out_dim = in_dim, out_dim
 
+    def materialize_input(self, fp_dim: int) -> None:
+        """Fix the input width from the width of ONE molecule vector (the MLP sees [g1 | g2])."""
+        (self.layers[0] if len(self.layers) else self.l_out).materialize(2 * fp_dim)
+        self.in_dim = 2 * fp_dim
+
     def _linears(self):
         return list(self.layers) + [self.l_out]
 
     def _kernel_ok(self) -> bool:
         ls = self._linears()
-        return (self.activation in (torch.relu, torch.nn.functional.relu) and len(ls) <= _MAXL and self.in_dim <= _MAXIN
+        return (self.activation in (torch.relu, torch.nn.functional.relu) and len(ls) <= _MAXL and self.in_dim is not None
+                and self.in_dim <= _MAXIN
                 and all(l.out_size <= _MAXW for l in ls))
 
     # ---- layout plan protocol (bmp/plan.py): identity layouts, the kernels write the gradients in place ----
@@ -163,6 +171,13 @@ class MLP(nn.Module):
 
     def forward(self, x, x2=None):
         """models/mlp.py:40-45.  ``x2``: optional second half of the input row ([x | x2] without the concatenation)."""
+        if self.in_dim is None:                                 # Chainer's lazy Linear: fixed by the first input
+            width = x.shape[-1] + (0 if x2 is None else x2.shape[-1])
+            (self.layers[0] if len(self.layers) else self.l_out).materialize(width)
+            self.in_dim = width
+        elif x.shape[-1] + (0 if x2 is None else x2.shape[-1]) != self.in_dim:
+            raise ValueError(f"MLP was built for {self.in_dim} input features, got "
+                             f"{x.shape[-1] + (0 if x2 is None else x2.shape[-1])}")
         ls = self._linears()
         if x.is_cuda and self._kernel_ok():
             fast = getattr(self, "_fast", None)

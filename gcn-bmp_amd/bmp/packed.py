@@ -129,6 +129,7 @@ class PackedMolBatch:
     max_rows_per_mol: int = 0
     mol_nrows_host: Optional[np.ndarray] = None   # host copy of mol_nrows (pair metadata without a device sync)
     row_mol: Optional[torch.Tensor] = None        # (N,) molecule of every row, -1 for rows of no molecule
+    atom_id_range: Tuple[int, int] = (0, 0)       # (min, max) atom id of the batch, known on the host at pack time
     _cache: dict = field(default_factory=dict, repr=False)
 
     @property
@@ -138,6 +139,13 @@ class PackedMolBatch:
     @property
     def device(self) -> torch.device:
         return self.atom_id.device
+
+    def check_atom_ids(self, n_atom_types: int) -> None:
+        """EmbedID's type check (chainer rejects ids outside the table; models/ggnn.py:85,603): raise before any kernel
+        indexes the embedding table.  The range was taken on the host when the batch was packed: no device sync."""
+        lo, hi = self.atom_id_range
+        if lo < 0 or hi >= n_atom_types:
+            raise ValueError(f"atom ids must lie in [0, {n_atom_types}); this batch has ids in [{lo}, {hi}]")
 
     def with_edge_vals(self, csr_val: torch.Tensor, csrT_val: torch.Tensor) -> "PackedMolBatch":
         import dataclasses
@@ -218,6 +226,7 @@ def _assemble(inst_nrows: np.ndarray, flat_atom: np.ndarray, flat_w: np.ndarray,
         n_real_atoms=int((inst_nrows - 1).sum()) if n_real_atoms is None else int(n_real_atoms), n_edges=int(len(e_dst)),
         max_rows_per_mol=int(inst_nrows.max()) if I else 0,
         mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[7],
+        atom_id_range=(int(flat_atom.min()), int(flat_atom.max())) if len(flat_atom) else (0, 0),
     )
 
 
@@ -412,7 +421,8 @@ def pack_from_dense_device(atom_arrays: Sequence, adjs: Sequence[torch.Tensor], 
         mol_row0=iv[3], mol_nrows=iv[4], side_tiles=tuple(side_tiles), side_mols=tuple(side_mols),
         dense_map=dmaps[0] if len(dmaps) == 1 else None, dense_maps=dmaps,
         n_real_atoms=int((inst_nrows - 1).sum()), n_edges=E, max_rows_per_mol=int(inst_nrows.max()) if I else 0,
-        mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[-1])
+        mol_nrows_host=inst_nrows.astype(np.int64), row_mol=iv[-1],
+        atom_id_range=(int(flat_atom.min()), int(flat_atom.max())) if len(flat_atom) else (0, 0))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -473,6 +483,7 @@ class DeviceMolStore:
         colT, rendT = local_csr(store.e_src, store.e_dst)
         host = [rowoff.astype(np.int32), eoff.astype(np.int32), store.atom_flat.astype(np.int32), rend, rendT, col, colT]
         self.host_arrays = host
+        self.atom_id_range = (int(store.atom_flat.min()), int(store.atom_flat.max()))      # bounds every batch's range
         self.plan_seconds, self.plan_calls = 0.0, 0
         if self.device.type == "cuda":
             buf = torch.from_numpy(np.concatenate(host)).to(self.device)
@@ -557,7 +568,7 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
         R=R, n_tiles=n_tiles, n_mols=I, atom_id=atom_id, row_w=row_w, csr_ptr=csr_ptr, csr_col=csr_col, csr_val=csr_val,
         csrT_ptr=csrT_ptr, csrT_col=csrT_col, csrT_val=csrT_val, mol_row0=up[:I], mol_nrows=up[I:2 * I],
         side_tiles=side_tiles, side_mols=side_mols, n_real_atoms=n_real, n_edges=E, max_rows_per_mol=max_rows,
-        mol_nrows_host=nrows_host, row_mol=row_mol)
+        mol_nrows_host=nrows_host, row_mol=row_mol, atom_id_range=dstore.atom_id_range)
     if paired:
         m = up[n_tab:n_tab + n_meta]
         top = max(k for k in range(4) if counts[k])

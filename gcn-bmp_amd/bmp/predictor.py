@@ -16,10 +16,22 @@ from .packed import PackedMolBatch
 class GraphConvPredictorForPair(nn.Module):
     def __init__(self, graph_conv, attn=None, mlp=None, symmetric=None):
         super().__init__()
+        # train_ddi_modify.py:47 declares (graph_conv, mlp=None) and calls GraphConvPredictorForPair(ggnn, mlp) (:150);
+        # train_binary.py:60 declares (graph_conv, attn=None, mlp=None, symmetric=None).  Both positional forms work:
+        if mlp is None and getattr(attn, "is_link_predictor", False):
+            attn, mlp = None, attn
         self.graph_conv = graph_conv
         self.attn = attn
         self.mlp = mlp
         self.symmetric = symmetric
+        # The reference builds its link predictors with Chainer's lazy input width (MLP(out_dim, hidden_dims),
+        # train_ddi_modify.py:136; SymMLP / HolE, train_binary.py:170,178).  The width is known here -- what the co-attention
+        # (or, without one, the encoder) hands over per molecule -- so the parameters exist before an optimizer flattens them.
+        fp = getattr(attn if attn is not None else graph_conv, "out_dim", None)
+        if attn is None and getattr(graph_conv, "concat_hidden", False):
+            fp = fp * graph_conv.n_layers                                   # models/ggnn.py:646-647
+        if fp is not None and callable(getattr(mlp, "materialize_input", None)):
+            mlp.materialize_input(int(fp))
 
     def _encode(self, atoms_1, adjs_1, atoms_2, adjs_2):
         """Siamese encoder (train_binary.py:91-94).  A two-sided PackedMolBatch in the first slot

@@ -188,6 +188,7 @@ class RelGCN(nn.Module):
 
     def _forward_fast(self, pb, fast):
         P, G, state, tape = fast
+        pb.check_atom_ids(P["embed.W"].shape[0])
         x = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
         pbs = rescale_adj(pb) if self.scale_adj else pb
         for l in range(len(self.rgcn_convs)):
@@ -209,6 +210,7 @@ class RelGCN(nn.Module):
         fast = getattr(self, "_fast", None)
         if fast is not None:
             return self._forward_fast(pb, fast)
+        pb.check_atom_ids(self.embed.W.shape[0])
         x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
         pbs = rescale_adj(pb) if self.scale_adj else pb
         for conv in self.rgcn_convs:
@@ -255,6 +257,7 @@ class GGNNModular(nn.Module):
             m = torch.as_tensor(np.asarray(is_real_node), dtype=torch.float32, device=pb.device)
             row_w = torch.zeros(pb.n_rows, device=pb.device).index_add_(0, pb.dense_map.reshape(-1), m.reshape(-1))
         self.reset_state()                                                       # models/models/ggnn.py:87
+        pb.check_atom_ids(self.embed.W.shape[0])
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
         h0 = h
         g_list = []

@@ -456,7 +456,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
             RM_LDS(Ys, v) = dz;
             rm_st<D, 7 * D>(b_o, v, dac, 6 * D);
             rm_st<D, 7 * D>(b_o, v, dz, 5 * D);
-            if (first) rm_st<D, 7 * D>(b_o, v, (f32x4){0.f, 0.f, 0.f, 0.f}, 4 * D);       // da_r = 0
+            // (first call after reset: no r gate, da_r = 0 -- its gda columns are neither written here nor read by
+            //  bmp_ggnn_step_wgrad)
         }
     }
     const float* const Ac_h = a.A + (size_t)(2 * D + 4 * hi) * 2 * D + 4 * col;
@@ -896,8 +897,35 @@ extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
 
+// The weight-gradient problems of one step as ONE fused launch (bmp_launch_wgrad_fused): all of them reduce over the
+// same N rows and read column ranges of the same gda rows.
+//   later steps:  o1 = h^T gda [d x 7d] (+ cs) | o2 = m^T gda[:, 4d:7d] [d x 3d] | dUcT = (r*h)^T gda[:, 6d:7d] [d x d]
+//   first step (no r gate, no U term: da_r = 0 and is neither written nor read): o1 skips columns [4d, 5d), o2 skips
+//   [0, d), dUcT is zero -- 6d + 2d instead of 7d + 3d + d columns of products.
+static int step_wgrad_problems(WGArgs* g, const float* h, const float* m, const float* rz, const float* gda, int N, int d,
+                               int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate) {
+    g[0] = WGArgs{h, nullptr, d, 0, gda, 7 * d, d, first ? 6 * d : 7 * d, N, o1, 7 * d, accumulate, cs};
+    g[1] = WGArgs{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, first ? 2 * d : 3 * d, N, o2, 3 * d, accumulate};
+    g[2] = WGArgs{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
+    if (first) {
+        g[0].skip_at = 4 * d; g[0].skip_n = d;
+        g[1].skip_at = 0; g[1].skip_n = d;
+        g[2].zero_only = 1;
+    }
+    return 3;
+}
+
+static bool step_wgrad_fusable(int N, int d) { return (d == 64 || d == 128) && (N & 31) == 0; }
+
 extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
-    return bmp_wgrad_ws_floats(N, d, 7 * d);
+    size_t a = bmp_wgrad_ws_floats(N, d, 7 * d);
+    if (step_wgrad_fusable(N, d)) {
+        WGArgs g[3];
+        const int n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0);
+        const size_t b = bmp_wgrad_fused_ws_floats(g, n);
+        if (b > a) a = b;
+    }
+    return a;
 }
 
 // Weight gradients of one step (reduction over all N = n_tiles*128 rows):
@@ -906,23 +934,26 @@ extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
 //   dUcT [d x d] = (r*h)^T . da_c   (zeros when first)
 //   cs [7d]      = column sums of gda: [dbE as e*d + c | db]
 // accumulate != 0 adds into the outputs (weight tying: one set of buffers for all steps).
+// first != 0: the da_r columns of gda are not read (bmp_ggnn_step_bwd does not write them) and count as zeros.
 extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
                                    int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
                                    size_t ws_floats, hipStream_t st) {
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
+    BMP_REQUIRE(h && m && rz && gda && o1 && o2 && dUcT && cs && ws);
+    if (step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)rz & 15) == 0 &&
+        ((uintptr_t)gda & 15) == 0) {
+        WGArgs g[3];
+        const int n = step_wgrad_problems(g, h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate);
+        return bmp_launch_wgrad_fused(g, n, ws, st, BMP_KID_WGRAD_STEP);
+    }
+    BMP_REQUIRE(!first);        // the unfused form below reads every column of gda: only for complete rows
     int rc;
     WGArgs g1{h, nullptr, d, 0, gda, 7 * d, d, 7 * d, N, o1, 7 * d, accumulate, cs};     // + column sums of gda
     if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
     WGArgs g2{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, 3 * d, N, o2, 3 * d, accumulate};
     if ((rc = bmp_launch_wgrad(g2, ws, st))) return rc;
-    if (!first) {
-        WGArgs g3{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
-        if ((rc = bmp_launch_wgrad(g3, ws, st))) return rc;
-    } else if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
+    WGArgs g3{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
+    return bmp_launch_wgrad(g3, ws, st);
 }
 
 // ---- fused RelGCN layer (d_in == d_out in {64, 128}) ----

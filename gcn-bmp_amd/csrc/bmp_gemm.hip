@@ -415,6 +415,7 @@ struct WGKArgs {
     int K, Nn, N, rows_per_split;
     float* slab;
     const int* onehot;      // if set, X is not read: X[row, k] = (onehot[row] == k)  (embedding gradient as a GEMM)
+    int skip_at = 0x7fffffff, skip_n = 0;     // logical column j reads dY column j + (j >= skip_at ? skip_n : 0)
 };
 
 template <int MB, int NB>
@@ -527,6 +528,7 @@ __device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, in
     const int nst = (r_end - r_begin) >> 5;
     const int c4 = tid & 31, rr = tid >> 5;
     const int colx = i_tile + 4 * c4, coly = j_tile + 4 * c4;
+    const int colyp = coly + (coly >= a.skip_at ? a.skip_n : 0);        // physical dY column
     const bool okx = colx < a.K, oky = coly < a.Nn;
     const bool do_cs = want_cs && bx == 0;
     const int Krows = a.K + (want_cs ? 1 : 0);
@@ -552,7 +554,7 @@ __device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, in
             xr[i] = okx ? *(const f32x4*)(a.X + row * a.ldx + colx) : zero4;                          \
             if (HAS_X2 && okx) xr[i] *= *(const f32x4*)(a.X2 + row * a.ldx2 + colx);                 \
         }                                                                                            \
-        yr[i] = oky ? *(const f32x4*)(a.dY + row * a.ldy + coly) : zero4;                             \
+        yr[i] = oky ? *(const f32x4*)(a.dY + row * a.ldy + colyp) : zero4;                            \
     }
 #define WG_STORE(buf)                                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
@@ -643,7 +645,47 @@ __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
     const int by = blockIdx.y;
     const int p = by >= m.ty0[2] ? 2 : (by >= m.ty0[1] ? 1 : 0);
     if ((int)blockIdx.z >= m.S[p]) return;
-    wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], blockIdx.z, XS, YS);
+    if (m.p[p].X2) wgrad_lds_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], blockIdx.z, XS, YS);
+    else wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], blockIdx.z, XS, YS);
+}
+
+// One reduction launch for the problems of a fused launch.  Walks the PHYSICAL output elements of every problem
+// ([Krows x Nn_phys], Krows = K + 1 with column sums): skipped columns and zero-only problems get zeros, the others
+// the fixed-order sum over the problem's slabs (same order as k_reduce_slabs: bitwise reproducible).
+struct RedProb {
+    const float* slab; int S, K, Krows, Nn, Nn_phys, skip_at, skip_n;
+    float* out; int ldo, accumulate; float* cs_out; int cs_accumulate;
+};
+struct RedMulti { RedProb p[3]; int b0[4]; };
+__global__ __launch_bounds__(256) void k_reduce_multi(RedMulti m) {
+    __shared__ float red[4][64];
+    const int bx = blockIdx.x;
+    const int pi = bx >= m.b0[2] ? 2 : (bx >= m.b0[1] ? 1 : 0);
+    const RedProb& q = m.p[pi];
+    const size_t total = (size_t)q.Krows * q.Nn_phys;
+    const size_t slab_sz = (size_t)q.Krows * q.Nn;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int nb = m.b0[pi + 1] - m.b0[pi];
+    for (size_t base = (size_t)(bx - m.b0[pi]) * 64; base < total; base += (size_t)nb * 64) {
+        const size_t idx = base + c;
+        const int i = (int)(idx / q.Nn_phys), jp = (int)(idx % q.Nn_phys);
+        const bool skipped = jp >= q.skip_at && jp < q.skip_at + q.skip_n;
+        const int jl = jp - (jp >= q.skip_at + q.skip_n ? q.skip_n : 0);
+        float v = 0.f;
+        if (idx < total && !skipped) {
+#pragma unroll 8
+            for (int s = g; s < q.S; s += 4) v += q.slab[(size_t)s * slab_sz + (size_t)i * q.Nn + jl];
+        }
+        red[g][c] = v;
+        __syncthreads();
+        if (g == 0 && idx < total) {
+            v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            const bool is_cs = i == q.K;
+            float* o = is_cs ? (q.cs_out + jp) : (q.out + (size_t)i * q.ldo + jp);
+            *o = (is_cs ? q.cs_accumulate : q.accumulate) ? (*o + v) : v;
+        }
+        __syncthreads();
+    }
 }
 
 static void wgrad_plan(int N, int K, int Nn, int& mb, int& nb, int& S, int& rps) {
@@ -799,6 +841,79 @@ int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
                            a[p].accumulate, m.want_cs[p] ? a[p].K : -1, a[p].cs, a[p].accumulate | a[p].cs_accumulate);
         BMP_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ---- fused form: all problems share the row range, one GEMM launch + one reduction launch ----
+static void wgrad_fused_plan(const WGArgs* a, int n, int* S, int* rps, int* ty0) {
+    int tiles = 0;
+    for (int p = 0; p < n; ++p) { ty0[p] = tiles; if (!a[p].zero_only) tiles += (a[p].Nn + 127) / 128; }
+    for (int p = n; p <= 3; ++p) ty0[p] = tiles;
+    for (int p = 0; p < n; ++p) {
+        int s = 512 / (tiles > 0 ? tiles : 1);        // 2 workgroups per CU and no second round
+        int max_s = a[p].N / 256;                     // at least 8 stages per split
+        if (max_s < 1) max_s = 1;
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+        int r = (a[p].N + s - 1) / s;
+        r = (r + 31) & ~31;
+        rps[p] = r; S[p] = a[p].zero_only ? 0 : (a[p].N + r - 1) / r;
+    }
+}
+
+size_t bmp_wgrad_fused_ws_floats(const WGArgs* a, int n) {
+    int S[3], rps[3], ty0[4];
+    wgrad_fused_plan(a, n, S, rps, ty0);
+    size_t tot = 0;
+    for (int p = 0; p < n; ++p) tot += (size_t)S[p] * (a[p].K + 1) * a[p].Nn;
+    return tot;
+}
+
+int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, int kid) {
+    BMP_REQUIRE(n >= 1 && n <= 3 && ws != nullptr);
+    WGKMulti m; memset(&m, 0, sizeof(m));
+    RedMulti r; memset(&r, 0, sizeof(r));
+    int rps[3];
+    for (int p = 0; p < n; ++p) {
+        BMP_REQUIRE(a[p].K <= 128 && !a[p].onehot && (a[p].zero_only || wgrad_use_lds(a[p])));
+        BMP_REQUIRE(a[p].skip_n == 0 || ((a[p].skip_at & 127) == 0 && (a[p].skip_n & 3) == 0));
+        BMP_REQUIRE(a[p].N == a[0].N);
+    }
+    wgrad_fused_plan(a, n, m.S, rps, m.ty0);
+    size_t off = 0;
+    int smax = 0, rb = 0;
+    double flops = 0, bytes = 0;
+    for (int p = 0; p < n; ++p) {
+        const int want_cs = a[p].cs != nullptr && !a[p].zero_only;
+        m.want_cs[p] = want_cs;
+        WGKArgs k{a[p].X, a[p].X2, a[p].ldx, a[p].ldx2, a[p].dY, a[p].ldy, a[p].K, a[p].Nn, a[p].N, rps[p], ws + off, nullptr};
+        k.skip_at = a[p].skip_at; k.skip_n = a[p].skip_n;
+        m.p[p] = k;
+        RedProb& q = r.p[p];
+        q.slab = ws + off; q.S = m.S[p]; q.K = a[p].K; q.Krows = a[p].K + want_cs; q.Nn = a[p].Nn;
+        q.Nn_phys = a[p].Nn + a[p].skip_n; q.skip_at = a[p].skip_n ? a[p].skip_at : 0x7fffffff; q.skip_n = a[p].skip_n;
+        q.out = a[p].out; q.ldo = a[p].ldo; q.accumulate = a[p].accumulate; q.cs_out = a[p].cs;
+        q.cs_accumulate = a[p].accumulate | a[p].cs_accumulate;
+        off += (size_t)m.S[p] * q.Krows * a[p].Nn;
+        if (m.S[p] > smax) smax = m.S[p];
+        if (!a[p].zero_only) {
+            flops += 2.0 * a[p].N * (double)a[p].K * a[p].Nn;
+            bytes += 4.0 * a[p].N * ((double)a[p].K + a[p].Nn);
+        }
+        r.b0[p] = rb;
+        int blocks = (int)(((size_t)q.Krows * q.Nn_phys + 63) / 64);
+        if (blocks > 1024) blocks = 1024;
+        if (a[p].zero_only && a[p].accumulate) blocks = 0;          // nothing to add
+        rb += blocks;
+    }
+    for (int p = n; p <= 3; ++p) r.b0[p] = rb;
+    if (m.ty0[3] > 0) {
+        BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, kid);
+        hipLaunchKernelGGL(k_wgrad_lds_multi, dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
+    }
+    BMP_LAUNCH_CHECK();
+    if (rb > 0) hipLaunchKernelGGL(k_reduce_multi, dim3(rb), dim3(256), 0, st, r);
+    BMP_LAUNCH_CHECK();
     return 0;
 }
 

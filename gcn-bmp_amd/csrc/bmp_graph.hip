@@ -5,13 +5,16 @@
 // ---------------------------------------------------------------------------------------------
 // embedding  (EmbedAtomID, models/ggnn.py:85,603): out[row, :] = W[ids[row], :]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ ids, const float* __restrict__ W, int N, int d,
+// An id outside [0, V) (the host wrappers reject such batches before any launch) reads row 0 instead of memory that
+// is not the table's.
+__global__ __launch_bounds__(256) void k_embed_fwd(const int* __restrict__ ids, const float* __restrict__ W, int N, int d, int V,
                                                    float* __restrict__ out) {
     const int d4 = d >> 2;
     const size_t total = (size_t)N * d4;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int row = (int)(idx / d4), c4 = (int)(idx % d4);
-        const int id = ids[row];
+        int id = ids[row];
+        if ((unsigned)id >= (unsigned)V) id = 0;
         *(f32x4*)(out + (size_t)row * d + 4 * c4) = *(const f32x4*)(W + (size_t)id * d + 4 * c4);
     }
 }
@@ -35,7 +38,11 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const int* __restrict__ ids, 
     for (int base = r0 + wave; base < r1; base += 32) {
         int id8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int row = base + 4 * u; id8[u] = row < r1 ? ids[row] : -1; }
+        for (int u = 0; u < 8; ++u) {
+            const int row = base + 4 * u;
+            id8[u] = row < r1 ? ids[row] : -1;
+            if (id8[u] >= V) id8[u] = -1;          // out-of-range ids contribute nothing (and touch no LDS)
+        }
         for (int c = lane; c < d; c += 64) {
             float v8[8];
 #pragma unroll
@@ -151,12 +158,12 @@ int bmp_launch_gather_bwd(const float* dagg, int N, int d, const int* ptrT, cons
 // ---------------------------------------------------------------------------------------------
 // C-ABI: embedding
 // ---------------------------------------------------------------------------------------------
-extern "C" int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float* out, hipStream_t st) {
-    BMP_REQUIRE(N > 0 && d > 0 && (d & 3) == 0);
+extern "C" int bmp_embed_fwd(const int* ids, const float* W, int N, int d, int V, float* out, hipStream_t st) {
+    BMP_REQUIRE(N > 0 && d > 0 && (d & 3) == 0 && V > 0 && ids && W && out);
     size_t total = (size_t)N * (d >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_embed_fwd, dim3(blocks), dim3(256), 0, st, ids, W, N, d, out);
+    hipLaunchKernelGGL(k_embed_fwd, dim3(blocks), dim3(256), 0, st, ids, W, N, d, V, out);
     BMP_LAUNCH_CHECK();
     return 0;
 }

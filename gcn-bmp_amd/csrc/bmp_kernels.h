@@ -62,12 +62,21 @@ struct WGArgs {
     float* cs;                       // optional [Nn]: column sums of dY (bias gradient), same accumulate flag
     int cs_accumulate;               // ... or accumulated regardless of `accumulate` when != 0
     const int* onehot;               // optional [N]: X is not read, X[row, k] = (onehot[row] == k)
+    // fused launches only (bmp_launch_wgrad_fused): the Nn LOGICAL columns skip the physical columns
+    // [skip_at, skip_at + skip_n) of dY and of out / cs (skip_at a multiple of 128 or 0; the skipped output columns
+    // are written as zeros unless accumulating); zero_only: no product at all, out is zero-filled unless accumulating
+    int skip_at = 0x7fffffff, skip_n = 0;
+    int zero_only = 0;
 };
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
 // n <= 3 independent problems (K <= 128, no X2) in ONE GEMM launch: for launches of a few tiles each
 size_t bmp_wgrad_multi_ws_floats(const WGArgs* a, int n);
 int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st);
+// n <= 3 problems over the SAME rows (K <= 128; X2, column skips and zero-only problems allowed) as ONE GEMM launch and
+// ONE reduction launch: the weight gradients of a fused GGNN step / RelGCN layer.
+size_t bmp_wgrad_fused_ws_floats(const WGArgs* a, int n);
+int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, int kid);
 
 // column sums: out[n] (=|+=) sum_rows dY[row, n]
 size_t bmp_colsum_ws_floats(int N, int Nn);
@@ -92,7 +101,7 @@ enum { BMP_KCLS_ROWGEMM = 1, BMP_KCLS_WGRAD = 2, BMP_KCLS_GATHER = 3, BMP_KCLS_C
        BMP_KCLS_STEP_BWD = 6, BMP_KCLS_ALL = -1 };
 // kernel ids inside a class (bmp_prof_collect reports per kernel: key = class * 16 + id)
 enum { BMP_KID_ROWGEMM = 0, BMP_KID_ROWGEMM_MULTI = 1, BMP_KID_READOUT_TILE = 2,
-       BMP_KID_WGRAD = 0, BMP_KID_WGRAD_X2 = 1, BMP_KID_WGRAD_ONEHOT = 2, BMP_KID_WGRAD_DIRECT = 3, BMP_KID_WGRAD_MULTI = 4,
+       BMP_KID_WGRAD = 0, BMP_KID_WGRAD_X2 = 1, BMP_KID_WGRAD_ONEHOT = 2, BMP_KID_WGRAD_DIRECT = 3, BMP_KID_WGRAD_MULTI = 4, BMP_KID_WGRAD_STEP = 5,
        BMP_KID_COATTN_FWD = 0, BMP_KID_COATTN_BWD = 1,
        BMP_KID_GGNN_LATER = 0, BMP_KID_GGNN_FIRST = 1, BMP_KID_RELGCN = 2 };
 struct BmpProfScope {

@@ -45,8 +45,10 @@ int bmp_prof_stop(double* out);
 int bmp_prof_collect(int* key, int* count, double* ms, double* flops, double* bytes, int cap);
 
 /* EmbedAtomID lookup -- chainer_chemistry EmbedAtomID used at models/ggnn.py:85,603
- * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:].  bwd accumulates INTO dW [V x d]. */
-int bmp_embed_fwd(const int* ids, const float* W, int N, int d, float* out, bmp_stream_t stream);
+ * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:], W [V x d].  Ids outside [0, V) are the caller's error (the Python
+ * wrappers raise ValueError before any launch, as chainer's EmbedID type check does); the kernels never leave the table:
+ * such a row reads W[0] and contributes nothing to dW. */
+int bmp_embed_fwd(const int* ids, const float* W, int N, int d, int V, float* out, bmp_stream_t stream);
 size_t bmp_embed_bwd_ws_floats(int N, int d, int V);
 int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, int V, float* dW, float* ws, size_t ws_floats,
                   bmp_stream_t stream);   /* dW is overwritten; two deterministic passes through ws */
@@ -86,7 +88,9 @@ int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float*
  * Uc [d x d] for bwd).  fwd saves m [N x d], rz [N x 2d], c [N x d].
  * bwd writes dh [N x d] and gda [N x 7d] = [G_0..G_3 (transposed-gathered dm per bond type) | da_r | da_z | da_c];
  * wgrad reduces over the N rows: o1 [d x 7d] = h^T.gda (cols [0,4d): dWT as [k][e*d+c]; cols [4d,7d): dAT rows
- * 0..d-1), o2 [d x 3d] = m^T.da (dAT rows d..2d-1), dUcT [d x d], cs [7d] = column sums (dbE | db). */
+ * 0..d-1), o2 [d x 3d] = m^T.da (dAT rows d..2d-1), dUcT [d x d], cs [7d] = column sums (dbE | db); all of it is ONE
+ * GEMM launch + ONE fixed-order reduction.  first != 0 (the GRU's first call after reset has no r gate): the da_r columns
+ * of gda are neither written by bwd nor read by wgrad and count as zeros. */
 int bmp_ggnn_step_supported(int d);
 int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
                       const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,

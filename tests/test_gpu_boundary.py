@@ -1,0 +1,146 @@
+"""The reference's own call forms on the GPU path, against the dense oracle:
+dense (mb, N, hid) atom arrays into the co-attention modules (nie_coattention.py:335-341; every position counts, the
+reference masks nothing), float atom features through the encoder (models/ggnn.py:600-605), the lazily sized MLP
+(train_ddi_modify.py:136), dropout in eval mode, retained-graph double backward."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _close(got, want, name, tol=1e-4):
+    got = got.detach().double().cpu(); want = want.detach().double()
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("attn", ["nie", "pool", "parallel", "alternating", "global", "neural"])
+def test_coattention_takes_dense_atom_arrays(attn):
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    d, o, mb, N1, N2 = 32, 16, 7, 19, 11
+    head = 1 if attn == "parallel" else 4
+    p = O.make_pair_params(777, hidden_dim=d, out_dim=o, n_layers=2, attn=attn, head=head, dtype=torch.float64, bias_scale=0.1)
+    model = build_pair_predictor(hidden_dim=d, out_dim=o, n_layers=2, attn=attn, head=head).to(dev)
+    load_param_dict(model, p)
+    rs = np.random.RandomState(0)
+    a1 = T(rs.normal(size=(mb, N1, d))).requires_grad_(); a2 = T(rs.normal(size=(mb, N2, d))).requires_grad_()
+    g1 = T(rs.normal(size=(mb, o))).requires_grad_(); g2 = T(rs.normal(size=(mb, o))).requires_grad_()
+    fn = {"nie": lambda: O.nie_coattention(p, a1, a2, "tanh", prefix="attn/"),
+          "pool": lambda: O.pooling_coattention(p, a1, a2, "tanh", prefix="attn/"),
+          "parallel": lambda: O.parallel_coattention(p, a1, g1, a2, g2, "tanh", prefix="attn/"),
+          "alternating": lambda: O.alternating_coattention(p, a1, g1, a2, g2, prefix="attn/"),
+          "global": lambda: O.global_coattention(p, a1, a2, prefix="attn/"),
+          "neural": lambda: O.neural_coattention(p, a1, a2, "tanh", prefix="attn/")}[attn]
+    c1o, c2o = fn()
+    wv = T(rs.normal(size=(mb, o)))
+    ((c1o * wv).sum() + (c2o * wv.flip(0)).sum()).backward()
+    x1 = a1.detach().float().to(dev).requires_grad_(); x2 = a2.detach().float().to(dev).requires_grad_()
+    h1 = g1.detach().float().to(dev).requires_grad_(); h2 = g2.detach().float().to(dev).requires_grad_()
+    c1, c2 = model.attn(x1, h1, x2, h2)                       # exactly the reference's call, train_binary.py:96
+    w = wv.float().to(dev)
+    ((c1 * w).sum() + (c2 * w.flip(0)).sum()).backward()
+    _close(c1, c1o, "compact_1"); _close(c2, c2o, "compact_2")
+    _close(x1.grad, a1.grad, "d atoms_1"); _close(x2.grad, a2.grad, "d atoms_2")
+    if g1.grad is not None:
+        _close(h1.grad, g1.grad, "d g_1"); _close(h2.grad, g2.grad, "d g_2")
+
+
+def test_float_atom_features_bypass_the_embedding():
+    from bmp import synth
+    from bmp.ggnn import GGNN
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    store = synth.make_store(9, seed=3, n_lo=3, n_hi=20, n_mean=9)
+    a, j = synth.concat_mols(store)
+    mb, A = a.shape
+    d = 64
+    p = O.make_pair_params(777, hidden_dim=d, out_dim=32, n_layers=3, attn=None, dtype=torch.float64)
+    sub = {k[len("graph_conv/"):]: v for k, v in p.items() if k.startswith("graph_conv/")}
+    rs = np.random.RandomState(1)
+    x = T(rs.normal(size=(mb, A, d)) * (a[:, :, None] != 0)).requires_grad_()        # zero features at padded positions
+    g_o, at_o = O.ggnn_forward(sub, x, T(j).double(), 3, True, prefix="")
+    wv = T(rs.normal(size=tuple(g_o.shape)))
+    (g_o * wv).sum().backward()
+    enc = GGNN(out_dim=32, hidden_dim=d, n_layers=3).to(dev)
+    load_param_dict(enc, sub)
+    xd = x.detach().float().to(dev).requires_grad_()
+    for adj in (j, T(j).to(dev)):                                  # host and device adjacency
+        xd.grad = None
+        g = enc(xd, adj)                                           # models/ggnn.py:600-605: a float array in the atoms slot
+        (g * wv.float().to(dev)).sum().backward()
+        _close(g, g_o, "g"); _close(enc.get_atom_array().dense(), at_o, "atoms"); _close(xd.grad, x.grad, "d features")
+    with pytest.raises(ValueError):
+        enc(torch.zeros(mb, A, d + 8, device=dev), j)
+
+
+def test_reference_construction_forms_train_on_the_gpu():
+    """set_up_predictor of train_ddi_modify.py:134-150, verbatim argument forms, then one optimizer step."""
+    from bmp import synth
+    from bmp.dp import FlatAdam
+    from bmp.ggnn import GGNN
+    from bmp.mlp import MLP
+    from bmp.predictor import GraphConvPredictorForPair
+    dev = torch.device("cuda:0")
+    mlp = MLP(out_dim=1, hidden_dims=(32, 16))
+    ggnn = GGNN(out_dim=16, hidden_dim=64, n_layers=2, concat_hidden=False, dropout_rate=0.0)
+    predictor = GraphConvPredictorForPair(ggnn, mlp).to(dev)
+    store = synth.make_store(12, seed=7, n_lo=3, n_hi=20, n_mean=9)
+    a1, j1 = synth.concat_mols(store[:6]); a2, j2 = synth.concat_mols(store[6:])
+    t = (torch.arange(6, device=dev) % 2).int().view(-1, 1)
+    opt = FlatAdam(predictor, alpha=1e-2)
+    losses = []
+    for _ in range(3):
+        y = opt.functional_forward(a1, j1, a2, j2)
+        loss = predictor.loss(y, t)
+        loss.backward()
+        opt.collect_grads(); opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    prob = predictor.predict(a1, j1, a2, j2)
+    assert prob.shape == (6, 1) and ((prob > 0) & (prob < 1)).all()
+
+
+def test_dropout_is_identity_in_eval_mode_and_refused_in_training():
+    from bmp import synth
+    from bmp.ggnn import GGNN
+    dev = torch.device("cuda:0")
+    store = synth.make_store(6, seed=9, n_lo=3, n_hi=12, n_mean=7)
+    a, j = synth.concat_mols(store)
+    torch.manual_seed(0)
+    enc0 = GGNN(out_dim=16, hidden_dim=64, n_layers=2).to(dev)
+    enc1 = GGNN(out_dim=16, hidden_dim=64, n_layers=2, dropout_rate=0.3).to(dev)
+    enc1.load_state_dict(enc0.state_dict())
+    enc1.eval()
+    with torch.no_grad():
+        assert torch.equal(enc0(a, j), enc1(a, j))
+    enc1.train()
+    with pytest.raises(NotImplementedError):
+        enc1(a, j)
+
+
+def test_second_backward_over_a_retained_graph_gives_the_same_weight_gradients():
+    """tied steps accumulate their weight gradients inside the kernels, driven by host-side counters; a second
+    backward over the same graph must start a fresh accumulation, not add to the first one's sums."""
+    from bmp import packed, synth
+    from bmp.ggnn import GGNN
+    dev = torch.device("cuda:0")
+    store = synth.make_store(10, seed=5, n_lo=3, n_hi=25, n_mean=10)
+    ms = packed.MolStore(store)
+    pb = packed.pack_from_store(ms, [np.arange(10)], device=dev)
+    torch.manual_seed(0)
+    enc = GGNN(out_dim=16, hidden_dim=64, n_layers=3).to(dev)
+    g = enc(pb)
+    loss = (g * g).sum()
+    params = list(enc.parameters())
+    first = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+    second = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+    for a, b, (name, _) in zip(first, second, enc.named_parameters()):
+        if a is not None:
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), name
