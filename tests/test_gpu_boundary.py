@@ -94,15 +94,21 @@ def test_reference_construction_forms_train_on_the_gpu():
     store = synth.make_store(12, seed=7, n_lo=3, n_hi=20, n_mean=9)
     a1, j1 = synth.concat_mols(store[:6]); a2, j2 = synth.concat_mols(store[6:])
     t = (torch.arange(6, device=dev) % 2).int().view(-1, 1)
-    opt = FlatAdam(predictor, alpha=1e-2)
+    y = predictor(a1, j1, a2, j2)                                 # eager call, exactly the reference's (train_ddi_modify.py:66)
+    predictor.loss(y, t).backward()
+    eager = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in predictor.parameters()]).clone()
+    opt = FlatAdam(predictor, alpha=1e-3)
     losses = []
-    for _ in range(3):
+    for k in range(6):
         y = opt.functional_forward(a1, j1, a2, j2)
         loss = predictor.loss(y, t)
         loss.backward()
-        opt.collect_grads(); opt.step()
-        losses.append(float(loss))
-    assert losses[-1] < losses[0]
+        opt.collect_grads()
+        if k == 0:
+            assert (opt.grad - eager).abs().max().item() <= 1e-5 * eager.abs().max().item()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
     prob = predictor.predict(a1, j1, a2, j2)
     assert prob.shape == (6, 1) and ((prob > 0) & (prob < 1)).all()
 
