@@ -22,16 +22,25 @@ from .packed import PackedMolBatch
 def rescale_adj(pb: PackedMolBatch) -> PackedMolBatch:
     """models/relgcn.py:20-28 on the packed batch: every bond value is divided by the SOURCE
     atom's degree (sum of adj over bond types and destination rows; 0 -> 1).  Index work +
-    one exact fp32 reciprocal-multiply per bond, same rounding as the reference's adj * (1/deg)."""
+    one exact fp32 reciprocal-multiply per bond, same rounding as the reference's adj * (1/deg).
+    One launch of bmp_rescale_adj on the device; host batches (CPU tests of the layout) take the same arithmetic in torch."""
     if "rescaled" in pb._cache:
         return pb._cache["rescaled"]
-    N = pb.n_rows
-    src = (pb.csr_col >> 2).long()
-    deg = torch.zeros(N, dtype=torch.float32, device=pb.device).index_add_(0, src, pb.csr_val)
-    inv = 1.0 / torch.where(deg != 0, deg, torch.ones_like(deg))
-    rowT = torch.repeat_interleave(torch.arange(N, device=pb.device), (pb.csrT_ptr[1:] - pb.csrT_ptr[:-1]).long())
-    out = dataclasses.replace(pb, csr_val=(pb.csr_val * inv[src]).contiguous(),
-                              csrT_val=(pb.csrT_val * inv[rowT]).contiguous(), _cache={})
+    N, E = pb.n_rows, pb.csr_col.numel()
+    if pb.csr_val.is_cuda:
+        from . import _lib
+        from ._lib import check, ptr, stream
+        vals = torch.empty(2, max(E, 1), dtype=torch.float32, device=pb.device)
+        check(_lib.lib().bmp_rescale_adj(ptr(pb.csr_col), ptr(pb.csr_val), E, ptr(pb.csrT_ptr), ptr(pb.csrT_val), N,
+                                         ptr(vals[0]), ptr(vals[1]), stream()), "bmp_rescale_adj")
+        out = dataclasses.replace(pb, csr_val=vals[0, :E], csrT_val=vals[1, :E], _cache={})
+    else:
+        src = (pb.csr_col >> 2).long()
+        deg = torch.zeros(N, dtype=torch.float32, device=pb.device).index_add_(0, src, pb.csr_val)
+        inv = 1.0 / torch.where(deg != 0, deg, torch.ones_like(deg))
+        rowT = torch.repeat_interleave(torch.arange(N, device=pb.device), (pb.csrT_ptr[1:] - pb.csrT_ptr[:-1]).long())
+        out = dataclasses.replace(pb, csr_val=(pb.csr_val * inv[src]).contiguous(),
+                                  csrT_val=(pb.csrT_val * inv[rowT]).contiguous(), _cache={})
     pb._cache["rescaled"] = out
     return out
 

@@ -207,3 +207,37 @@ extern "C" int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, con
     BMP_LAUNCH_CHECK();
     return 0;
 }
+
+// rescale_adj (models/relgcn.py:20-28) on the packed CSR: every bond value is divided by the degree of its SOURCE atom
+// (sum of adj over bond types and destination rows; 0 -> 1), as value * (1 / degree) -- the reference's rounding.  A source's
+// bonds are one row of the transposed CSR, so its degree is that row's sum (a handful of entries): every thread recomputes
+// the degree it needs, in the row's order, and no pass over a degree array is needed.
+//   threads [0, E): entry t of the CSR;   threads [E, E + N): row (t - E) of the transposed CSR.
+__global__ __launch_bounds__(256) void k_rescale_adj(const int* __restrict__ csr_col, const float* __restrict__ csr_val, int E,
+                                                     const int* __restrict__ csrT_ptr, const float* __restrict__ csrT_val, int N,
+                                                     float* __restrict__ out, float* __restrict__ outT) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < E) {
+        const int src = csr_col[t] >> 2;
+        float deg = 0.f;
+        for (int k = csrT_ptr[src]; k < csrT_ptr[src + 1]; ++k) deg += csrT_val[k];
+        out[t] = csr_val[t] * (1.0f / (deg != 0.f ? deg : 1.0f));
+    } else if (t < E + N) {
+        const int j = t - E;
+        const int k0 = csrT_ptr[j], k1 = csrT_ptr[j + 1];
+        float deg = 0.f;
+        for (int k = k0; k < k1; ++k) deg += csrT_val[k];
+        const float inv = 1.0f / (deg != 0.f ? deg : 1.0f);
+        for (int k = k0; k < k1; ++k) outT[k] = csrT_val[k] * inv;
+    }
+}
+
+extern "C" int bmp_rescale_adj(const int* csr_col, const float* csr_val, int E, const int* csrT_ptr, const float* csrT_val, int N,
+                               float* csr_val_out, float* csrT_val_out, hipStream_t st) {
+    BMP_REQUIRE(E >= 0 && N > 0 && csrT_ptr && (E == 0 || (csr_col && csr_val && csrT_val && csr_val_out && csrT_val_out)));
+    if (E == 0) return 0;
+    hipLaunchKernelGGL(k_rescale_adj, dim3((E + N + 255) / 256), dim3(256), 0, st, csr_col, csr_val, E, csrT_ptr, csrT_val, N,
+                       csr_val_out, csrT_val_out);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}

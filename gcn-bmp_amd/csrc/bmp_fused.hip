@@ -940,18 +940,27 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
                                    size_t ws_floats, hipStream_t st) {
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
     BMP_REQUIRE(h && m && rz && gda && o1 && o2 && dUcT && cs && ws);
-    if (step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)rz & 15) == 0 &&
+    static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;        // A/B switch (tools, tests)
+    if (!unfused && step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)rz & 15) == 0 &&
         ((uintptr_t)gda & 15) == 0) {
         WGArgs g[3];
         const int n = step_wgrad_problems(g, h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate);
         return bmp_launch_wgrad_fused(g, n, ws, st, BMP_KID_WGRAD_STEP);
     }
-    BMP_REQUIRE(!first);        // the unfused form below reads every column of gda: only for complete rows
+    // one launch per product (first steps: the da_r columns of gda are not written, so they are zeroed here first)
     int rc;
+    if (first) {
+        hipError_t e = hipMemset2DAsync(const_cast<float*>(gda) + 4 * d, (size_t)7 * d * sizeof(float), 0, (size_t)d * sizeof(float), N, st);
+        if (e != hipSuccess) return (int)e;
+    }
     WGArgs g1{h, nullptr, d, 0, gda, 7 * d, d, 7 * d, N, o1, 7 * d, accumulate, cs};     // + column sums of gda
     if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;
     WGArgs g2{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, 3 * d, N, o2, 3 * d, accumulate};
     if ((rc = bmp_launch_wgrad(g2, ws, st))) return rc;
+    if (first) {
+        if (!accumulate) { hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+        return 0;
+    }
     WGArgs g3{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
     return bmp_launch_wgrad(g3, ws, st);
 }

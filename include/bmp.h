@@ -237,6 +237,11 @@ int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, const int* st_
                      int* csr_ptr, int* csr_col, float* csr_val, int* csrT_ptr, int* csrT_col, float* csrT_val,
                      bmp_stream_t stream);
 
+/* rescale_adj -- models/relgcn.py:20-28 on the packed CSR: csr_val_out[e] = csr_val[e] * (1 / deg(source of e)), and the
+ * same for the transposed CSR; deg = sum of the source atom's bond values over types and destinations (0 -> 1). */
+int bmp_rescale_adj(const int* csr_col, const float* csr_val, int E, const int* csrT_ptr, const float* csrT_val, int N,
+                    float* csr_val_out, float* csrT_val_out, bmp_stream_t stream);
+
 /* ---- link predictor tail: MLP (models/mlp.py:20-45: Linear -> relu -> ... -> Linear on [g1 | g2], train_binary.py:98-101)
  * and sigmoid cross entropy (chainer.functions.sigmoid_cross_entropy, train_ddi_modify.py:285) ----
  * x = [x1 (B x d1) | x2 (B x d2)] (x2 NULL when d2 = 0); dims[0..nl] layer widths (dims[0] = d1 + d2 <= 1024, the others
