@@ -65,6 +65,10 @@ SIGNATURES = {
     "bmp_collate_plan": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P]),
     "bmp_collate_pair_meta": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "bmp_collate_emit": (_I, [_P, _I] + [_P] * 16 + [_P]),
+    "bmp_bimpm_supported": (_I, [_I, _I, _I]),
+    "bmp_bimpm_ws_floats": (_Z, [_I, _I, _I, _I, _I]),
+    "bmp_bimpm_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_bimpm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "bmp_rescale_adj": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),

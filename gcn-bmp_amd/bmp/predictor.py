@@ -101,6 +101,9 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
     if attn in ("nie", "vqa"):
         from .coattention import NieFineCoattention
         a = NieFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
+    elif attn == "bimpm":                                                        # train_binary.py:253-256: head = fp_out_dim
+        from .bimpm import BiMPM
+        a = BiMPM(hidden_dim=hidden_dim, out_dim=out_dim, head=head, with_max_pool=True, with_att_mean=True, with_att_max=True)
     elif attn in ("deep", "very-deep", "extreme-deep"):                         # train_binary.py:229-247
         from . import coattention as C
         cls = {"deep": C.DeepNieFineCoattention, "very-deep": C.VeryDeepNieFineCoattention,
@@ -129,4 +132,5 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
         a = NeuralCoattention(hidden_dim=hidden_dim, out_dim=out_dim, activation="tanh")
     elif attn is not None:
         raise ValueError('[ERROR] Invalid Co-Attention Method.')
-    return GraphConvPredictorForPair(enc, a, build_link_predictor(sim_method, out_dim, class_num, mlp_hidden))
+    fp_dim = getattr(a, "out_dim", out_dim) if a is not None else out_dim        # BiMPM hands over 3 * head columns
+    return GraphConvPredictorForPair(enc, a, build_link_predictor(sim_method, fp_dim, class_num, mlp_hidden))

@@ -208,6 +208,22 @@ int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, 
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
                        bmp_stream_t stream);
 
+/* ---- BiMPM matching -- models/coattention/bimpm.py:45-199 with aggr = F.sum (train_binary.py:253-256) ----
+ * mol_1, mol_2 [B x 3H] for B drug pairs: max-pooling matching, attentive-mean matching and attentive-max matching of every
+ * atom against the other molecule, `H` perspectives each, summed over the atoms (with the row multiplicities w of the packed
+ * layout; maxima over rows with w > 0).  X1 / X2 [N x d]: packed atom rows of the two sides; r / n: first row and row count
+ * of every pair's molecule (n <= maxn); P, Q, R [H x d] = max_pooling_W, att_mean_W, att_max_W.  The backward recomputes the
+ * forward (same order: the same maxima win) and overwrites dP, dQ, dR and the rows of dX1 / dX2 that belong to a pair. */
+int bmp_bimpm_supported(int d, int H, int maxn);
+size_t bmp_bimpm_ws_floats(int d, int H, int maxn, int B, int backward);
+int bmp_bimpm_fwd(const float* X1, const float* X2, int d, int H, const float* w1, const int* r1, const int* n1, const float* w2,
+                  const int* r2, const int* n2, int B, int maxn, const float* P, const float* Q, const float* R, float* out1,
+                  float* out2, float* ws, size_t ws_floats, bmp_stream_t stream);
+int bmp_bimpm_bwd(const float* dout1, const float* dout2, const float* X1, const float* X2, int d, int H, const float* w1,
+                  const int* r1, const int* n1, const float* w2, const int* r2, const int* n2, int B, int maxn, const float* P,
+                  const float* Q, const float* R, float* dX1, float* dX2, float* dP, float* dQ, float* dR, float* ws,
+                  size_t ws_floats, bmp_stream_t stream);
+
 /* ---- the reference's dense batch on the device (concat_mols, train_ddi_modify.py:296) ----
  * adj (mb, 4, A, A) float32, zero padded.  bmp_dense_count: bonds per dense position, by row (incoming) and by column
  * (outgoing).  bmp_dense_to_csr: the entries of the packed CSR of bmp/packed.py (transposed = 1: of its transpose), in

@@ -301,6 +301,72 @@ def pooling_coattention(p: Params, atoms_1: Tensor, atoms_2: Tensor, activation:
     return (attn_1 * j1).sum(dim=1), (attn_2 * j2).sum(dim=1)
 
 
+def l2_normalize(x: Tensor, dim: int, eps: float = 1e-5) -> Tensor:
+    """chainer.functions.normalize(x, eps=1e-5, axis): x / (||x||_2 + eps) along ``axis`` (the eps is added to the norm,
+    not clamped; SURVEY.md Appendix B: third-party semantics restated from memory)."""
+    return x / (torch.sqrt((x * x).sum(dim=dim, keepdim=True)) + eps)
+
+
+def bimpm_coattention(p: Params, atoms_1: Tensor, atoms_2: Tensor, prefix: str = "", with_max_pool: bool = True,
+                      with_att_mean: bool = True, with_att_max: bool = True) -> Tuple[Tensor, Tensor]:
+    """BiMPM.__call__ models/coattention/bimpm.py:45-199 with aggr = F.sum (its only use, train_binary.py:255-256),
+    op for op.  Returns (mol_1, mol_2) of shape (mb, n_match * head): the reference never applies an out layer (:35).
+    Restated as written, including what looks unintended: mp_matching_func (:50-79) takes column 0 of the
+    (head x head) product, so perspective k of v1 is compared with perspective 0 of v2."""
+    mb, N_1, d = atoms_1.shape
+    N_2 = atoms_2.shape[1]
+
+    def mp_matching_func(v1, v2, w):                                   # :50-79
+        head = w.shape[0]
+        wt = w.t()[None, None]                                         # (1, 1, d, head)
+        v1e = wt * v1[..., None]                                       # (mb, N, d, head)
+        if v2.dim() == 3:
+            v2e = wt * v2[..., None]
+        else:
+            v2e = wt * v2[:, None, :, None].expand(-1, v1.shape[1], -1, head)
+        v1n, v2n = l2_normalize(v1e, 2), l2_normalize(v2e, 2)          # :73-74 normalised over hidden_dim
+        sim = torch.matmul(v1n.transpose(2, 3), v2n)                   # (mb, N, head, head) :76
+        return sim[:, :, :, 0]                                         # :78
+
+    def mp_matching_func_pairwise(v1, v2, w):                          # :81-105
+        we = w[None, :, None, :]                                       # (1, head, 1, d)
+        v1n = l2_normalize(we * v1[:, None], 3)                        # (mb, head, N_1, d)
+        v2n = l2_normalize(we * v2[:, None], 3)
+        sim = torch.matmul(v1n, v2n.transpose(2, 3))                   # (mb, head, N_1, N_2)
+        return sim.permute(0, 2, 3, 1)                                 # (mb, N_1, N_2, head)
+
+    def div_with_small_value(n, dd, eps=1e-4):                         # :122-124
+        return n / torch.maximum(dd, torch.full_like(dd, eps))
+
+    mv1, mv2 = [], []
+    if with_max_pool:                                                  # :132-142
+        mv_max = mp_matching_func_pairwise(atoms_1, atoms_2, p[f"{prefix}max_pooling_W"])
+        mv1.append(mv_max.max(dim=2).values)
+        mv2.append(mv_max.max(dim=1).values)
+    if with_att_mean or with_att_max:
+        att = torch.matmul(l2_normalize(atoms_1, 2), l2_normalize(atoms_2, 2).transpose(1, 2))     # :107-120 (mb, N_1, N_2)
+        att_atoms2 = atoms_2[:, None, :, :] * att[..., None]           # (mb, N_1, N_2, d) :150
+        att_atoms1 = atoms_1[:, :, None, :] * att[..., None]           # :154
+        if with_att_mean:                                              # :156-167
+            mean2 = div_with_small_value(att_atoms2.sum(dim=2), att.sum(dim=2, keepdim=True))
+            mean1 = div_with_small_value(att_atoms1.sum(dim=1), att.sum(dim=1, keepdim=True).transpose(1, 2))
+            mv1.append(mp_matching_func(atoms_1, mean2, p[f"{prefix}att_mean_W"]))
+            mv2.append(mp_matching_func(atoms_2, mean1, p[f"{prefix}att_mean_W"]))
+        if with_att_max:                                               # :169-182
+            max2 = att_atoms2.max(dim=2).values
+            max1 = att_atoms1.max(dim=1).values
+            mv1.append(mp_matching_func(atoms_1, max2, p[f"{prefix}att_max_W"]))
+            mv2.append(mp_matching_func(atoms_2, max1, p[f"{prefix}att_max_W"]))
+    mv1, mv2 = torch.cat(mv1, dim=2), torch.cat(mv2, dim=2)            # :185-187
+    return mv1.sum(dim=1), mv2.sum(dim=1)                              # :190-192 aggr = F.sum over atoms
+
+
+def init_bimpm(dr: "_Draw", prefix: str, hidden_dim: int, head: int) -> None:
+    """bimpm.py:24-33: three (head, hidden_dim) parameters, HeNormal (std = sqrt(2 / fan_in), fan_in = hidden_dim)."""
+    for name in ("max_pooling_W", "att_mean_W", "att_max_W"):
+        dr.normal(f"{prefix}{name}", (head, hidden_dim), math.sqrt(2.0 / hidden_dim))
+
+
 # --------------------------------------------------------------------------- #
 # coarse co-attention family (atom x molecule-vector)
 # --------------------------------------------------------------------------- #
@@ -499,6 +565,8 @@ def pair_forward(p: Params, atoms_1: Tensor, adjs_1: Tensor, atoms_2: Tensor, ad
         g1, g2 = global_coattention(p, at1, at2, prefix="attn/")
     elif attn == "neural":
         g1, g2 = neural_coattention(p, at1, at2, attn_activation, prefix="attn/")
+    elif attn == "bimpm":
+        g1, g2 = bimpm_coattention(p, at1, at2, prefix="attn/")
     elif attn is not None:
         raise ValueError(attn)
     y = mlp_forward(p, torch.cat((g1, g2), dim=-1), mlp_hidden)
@@ -684,6 +752,10 @@ def make_pair_params(seed: int = 777, *, encoder: str = "ggnn", hidden_dim: int 
         init_global(dr, "attn/", hidden_dim, out_dim)
     elif attn == "neural":
         init_neural(dr, "attn/", hidden_dim, out_dim)
+    elif attn == "bimpm":
+        init_bimpm(dr, "attn/", hidden_dim, head)                     # train_binary.py:255: head = fp_out_dim there
+        init_mlp(dr, "mlp/", 2 * 3 * head, class_num, mlp_hidden)     # three matchings of `head` perspectives per side
+        return dr.p
     init_mlp(dr, "mlp/", 2 * out_dim, class_num, mlp_hidden)
     return dr.p
 
