@@ -6,7 +6,7 @@ produced by ``oracle/ref_cpu.py`` (PARITY UNPINNED, see its header).  They pin
 the oracle against regressions and give the GPU tests committed
 inputs/outputs that do not depend on anything outside the repo.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [name filter ...]
 """
 import os
 import sys
@@ -40,7 +40,12 @@ def grads_of(loss, p):
     return {f"grad:{n}": (g if g is not None else torch.zeros_like(p[n])).numpy() for n, g in zip(names, gs)}
 
 
+ONLY = sys.argv[1:]          # optional name filters: write only the files whose name contains one of them
+
+
 def save(name, **arrs):
+    if ONLY and not any(f in name for f in ONLY):
+        return
     np.savez_compressed(os.path.join(HERE, name), **arrs)
     print(name, {k: v.shape for k, v in arrs.items() if not k.startswith(("param:", "grad:"))})
 
@@ -98,7 +103,8 @@ def main():
          **{f"param:{k}": v.detach().numpy() for k, v in p.items()}, **grads_of(loss, p))
 
     # ---- the other co-attention families on the same three pairs (GGNN 2 x 8 encoder, head 8 / 1) ------------
-    for k, attn in enumerate(("deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural")):
+    for k, attn in enumerate(("deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural",
+                              "bimpm")):
         p = O.make_pair_params(790 + k, hidden_dim=8, out_dim=8, n_layers=2, attn=attn, head=8, dtype=torch.float64)
         p = {kk: v.requires_grad_() for kk, v in p.items()}
         y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn=attn)

@@ -233,7 +233,7 @@ def test_pooling_coattention_pair(pairs, d, act):
         close(gr, ref, f"grad {name}", floor=floor)
 
 
-@pytest.mark.parametrize("attn", ["parallel", "circ", "alternating", "global", "neural"])
+@pytest.mark.parametrize("attn", ["parallel", "circ", "alternating", "global", "neural", "bimpm"])
 @pytest.mark.parametrize("joint", [True, False])
 def test_coarse_coattention_pair(pairs, attn, joint):
     """Coarse (atom x molecule-vector) co-attention family through the pair predictor vs the dense oracle,
@@ -292,7 +292,7 @@ def test_folded_fine_variants_through_the_pair_predictor(pairs, attn):
         close(gr, ref, f"grad {name}")
 
 
-@pytest.mark.parametrize("attn", ["deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural"])
+@pytest.mark.parametrize("attn", ["deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural", "bimpm"])
 def test_pair_golden_other_coattention(golden_dir, attn):
     """Committed float64 vectors of every co-attention family (tests/golden/make_golden.py), reference call form
     (four dense arrays)."""

@@ -59,7 +59,7 @@ def test_golden_pair(golden_dir, name, enc, nl):
     _check_grads(loss, p, gref)
 
 
-ATTN_GOLDEN = ["deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural"]
+ATTN_GOLDEN = ["deep", "extreme-deep", "fourier", "circ", "pool", "parallel", "alternating", "global", "neural", "bimpm"]
 
 
 @pytest.mark.parametrize("attn", ATTN_GOLDEN)
@@ -255,3 +255,41 @@ def test_pair_forward_with_the_added_coattention_variants(attn):
     y, g1, g2 = O.pair_forward(p, torch.from_numpy(a1), torch.from_numpy(j1).double(), torch.from_numpy(a2),
                                torch.from_numpy(j2).double(), n_layers=2, attn=attn)
     assert y.shape == (3, 1) and g1.shape == (3, 8) and torch.isfinite(y).all()
+
+
+# ---- BiMPM (models/coattention/bimpm.py): known answers of the restatement ----
+def _bimpm_params(H, d, seed=0):
+    rs = np.random.RandomState(seed)
+    return {f"{n}": T(rs.normal(size=(H, d))) for n in ("max_pooling_W", "att_mean_W", "att_max_W")}
+
+
+def test_bimpm_single_atom_pair_by_hand():
+    """One atom per molecule: every max / mean is over one element, so all three matchings are closed forms."""
+    H, d = 3, 4
+    p = _bimpm_params(H, d)
+    rs = np.random.RandomState(1)
+    x, y = rs.normal(size=d), rs.normal(size=d)
+    m1, m2 = O.bimpm_coattention(p, T(x).view(1, 1, d), T(y).view(1, 1, d))
+    eps = 1e-5
+    m = lambda u, v: float(u @ v / ((np.linalg.norm(u) + eps) * (np.linalg.norm(v) + eps)))
+    P, Q, R = (p[n].numpy() for n in ("max_pooling_W", "att_mean_W", "att_max_W"))
+    att = m(x, y)
+    mean2 = att * y / max(att, 1e-4); mean1 = att * x / max(att, 1e-4)          # div_with_small_value, bimpm.py:122-124
+    want1 = [m(P[k] * x, P[k] * y) for k in range(H)] + [m(Q[k] * x, Q[0] * mean2) for k in range(H)] + \
+            [m(R[k] * x, R[0] * (att * y)) for k in range(H)]                  # perspective 0 on the attended vector (:76-78)
+    want2 = [m(P[k] * y, P[k] * x) for k in range(H)] + [m(Q[k] * y, Q[0] * mean1) for k in range(H)] + \
+            [m(R[k] * y, R[0] * (att * x)) for k in range(H)]
+    assert np.allclose(m1.numpy().ravel(), want1, rtol=1e-12) and np.allclose(m2.numpy().ravel(), want2, rtol=1e-12)
+
+
+def test_bimpm_is_invariant_to_atom_order_and_swaps_with_the_sides():
+    H, d = 4, 6
+    p = _bimpm_params(H, d, 2)
+    rs = np.random.RandomState(3)
+    a1, a2 = T(rs.normal(size=(2, 5, d))), T(rs.normal(size=(2, 7, d)))
+    m1, m2 = O.bimpm_coattention(p, a1, a2)
+    q1, q2 = O.bimpm_coattention(p, a1[:, rs.permutation(5)], a2[:, rs.permutation(7)])
+    assert torch.allclose(m1, q1, rtol=1e-12, atol=1e-13) and torch.allclose(m2, q2, rtol=1e-12, atol=1e-13)
+    s2, s1 = O.bimpm_coattention(p, a2, a1)                                   # the module is symmetric in its two sides
+    assert torch.allclose(m1, s1, rtol=1e-12, atol=1e-13) and torch.allclose(m2, s2, rtol=1e-12, atol=1e-13)
+    assert m1.shape == (2, 3 * H)
