@@ -639,6 +639,9 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
 // every one of them lasts one workgroup's latency, side by side they share it.  ONE staging area: an LDS array per
 // instantiated body would halve the workgroups per CU.
 struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; };
+// STEP = 1: the launch of bmp_launch_wgrad_fused (same code; a separate symbol so that profiles tell the fused step
+// weight gradients from the co-attention's small three-problem launch)
+template <int STEP>
 __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
     __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
     __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
@@ -829,7 +832,7 @@ int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
     }
     {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, BMP_KID_WGRAD_MULTI);
-        hipLaunchKernelGGL(k_wgrad_lds_multi, dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
+        hipLaunchKernelGGL((k_wgrad_lds_multi<0>), dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
     }
     BMP_LAUNCH_CHECK();
     for (int p = 0; p < n; ++p) {
@@ -909,7 +912,7 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
     for (int p = n; p <= 3; ++p) r.b0[p] = rb;
     if (m.ty0[3] > 0) {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, kid);
-        hipLaunchKernelGGL(k_wgrad_lds_multi, dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
+        hipLaunchKernelGGL((k_wgrad_lds_multi<1>), dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
     }
     BMP_LAUNCH_CHECK();
     if (rb > 0) hipLaunchKernelGGL(k_reduce_multi, dim3(rb), dim3(256), 0, st, r);

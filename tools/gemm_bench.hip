@@ -25,6 +25,14 @@ __global__ __launch_bounds__(512) void k_big(const float* __restrict__ X, const 
     for (int rb = 0; rb < 2; ++rb) for (int cb = 0; cb < 4; ++cb) for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
     f32x4 sa[4], sb[4];
     for (int i = 0; i < 4; ++i) { sa[i] = (f32x4){1.f, 2.f, 3.f, 4.f}; sb[i] = (f32x4){.5f, .25f, .125f, 1.f}; }
+    if (MODE & 128) {          // pseudo-random register operands: the data-dependent (power / clock) share without any memory traffic
+        unsigned h = (tid + 977u * blockIdx.x + 131071u * blockIdx.y) * 2654435761u;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; sa[i][j] = ((h & 0xFFFF) / 32768.0f - 1.0f) * 0.7f;
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; sb[i][j] = ((h & 0xFFFF) / 32768.0f - 1.0f) * 0.7f;
+            }
+    }
     const int bk4 = tid >> 6, bnq = tid & 63;
     if (MODE & 64) { if (w >= 4) __builtin_amdgcn_s_setprio(1); }
     auto load_chunk = [&](int k0_) {
@@ -151,6 +159,8 @@ int main(int argc, char** argv) {
     run<1 | 2 | 8>("no loads, no stores, no barrier", X, W, Y, N, K, Nout);
     run<1 | 2 | 4 | 8>("MFMA only", X, W, Y, N, K, Nout);
     run<1 | 2 | 4 | 8 | 16>("MFMA only (double-buffer form)", X, W, Y, N, K, Nout);
+    run<1 | 128>("no global loads, RANDOM operands", X, W, Y, N, K, Nout);
+    run<1 | 2 | 4 | 8 | 128>("MFMA only, RANDOM operands", X, W, Y, N, K, Nout);
     run<32>("full + stagger", X, W, Y, N, K, Nout);
     run<64>("full + waves 4-7 prio 1", X, W, Y, N, K, Nout);
     run<16 | 64>("full + frag db + prio", X, W, Y, N, K, Nout);

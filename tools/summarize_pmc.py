@@ -32,6 +32,16 @@ for name, cs in acc.items():
     for c, (s, n) in sorted(cs.items()):
         e[c + "_per_launch"] = s / n
     res[name] = e
+# provenance for bench.py: traffic figures are only quoted for the library version and configuration they were measured on
+import subprocess
+tag = {"_config": os.environ.get("BMP_PROFILE_CONFIG", "c2")}
+try:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gcn-bmp_amd"))
+    from bmp import _lib
+    tag["_bmp_version"] = int(_lib.lib().bmp_version())
+except Exception as e:                               # noqa: BLE001
+    tag["_bmp_version"] = None
+res.update(tag)
 json.dump(res, open(out, "w"), indent=1)
-for name, e in sorted(res.items(), key=lambda kv: -kv[1]["avg_us_profiled"] * kv[1]["launches"])[:12]:
+for name, e in sorted(((k, v) for k, v in res.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["avg_us_profiled"] * kv[1]["launches"])[:12]:
     print(name, json.dumps(e))
