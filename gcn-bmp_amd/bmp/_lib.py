@@ -32,6 +32,9 @@ SIGNATURES = {
     "bmp_gru_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bmp_gru_bwd_ws_floats": (_Z, [_I, _I]),
     "bmp_gru_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_gru_state_fwd": (_I, [_P, _P, _P, _I, _I] + [_P] * 8),
+    "bmp_gru_state_bwd_ws_floats": (_Z, [_I, _I]),
+    "bmp_gru_state_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11 + [_Z, _P]),
     "bmp_ggnn_step_supported": (_I, [_I]),
     "bmp_ggnn_step_fwd": (_I, [_P, _I, _I, _I] + [_P] * 13),
     "bmp_ggnn_step_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I] + [_P] * 9),

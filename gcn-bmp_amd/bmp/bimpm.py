@@ -51,7 +51,8 @@ class BiMPMFn(Function):
         dP, dQ, dR = torch.empty_like(P), torch.empty_like(Q), torch.empty_like(R)
         nws = L.bmp_bimpm_ws_floats(d, H, maxn, B, 1)
         ws = torch.empty(nws, dtype=torch.float32, device=X1.device)
-        check(L.bmp_bimpm_bwd(ptr(d1.contiguous()), ptr(d2.contiguous()), ptr(X1), ptr(X2), d, H, ptr(w1), ptr(meta["r1"]),
+        d1, d2 = d1.contiguous(), d2.contiguous()                      # bound to names: a temporary would be freed before the launch
+        check(L.bmp_bimpm_bwd(ptr(d1), ptr(d2), ptr(X1), ptr(X2), d, H, ptr(w1), ptr(meta["r1"]),
                               ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), B, maxn, ptr(P), ptr(Q), ptr(R),
                               ptr(dX1), ptr(dX2), ptr(dP), ptr(dQ), ptr(dR), ptr(ws), nws, stream()), "bmp_bimpm_bwd")
         return dX1, dX2, dP, dQ, dR, None, None, None, None

@@ -48,7 +48,8 @@ class SegPoolFn(Function):
         A, Y, w, row0, nrows = ctx.saved_tensors
         N, o = Y.shape
         dA, dY = torch.empty_like(A), torch.empty_like(Y)
-        check(L.bmp_segpool_bwd(ptr(dout.contiguous()), ptr(A), A.shape[1], ptr(Y), o, ptr(w), ptr(row0), ptr(nrows),
+        dout = dout.contiguous()
+        check(L.bmp_segpool_bwd(ptr(dout), ptr(A), A.shape[1], ptr(Y), o, ptr(w), ptr(row0), ptr(nrows),
                                 row0.numel(), N, ptr(dA), ptr(dY), stream()), "bmp_segpool_bwd")
         return dA, dY, None, None, None
 
@@ -69,7 +70,8 @@ class SegSoftmaxFn(Function):
         L = _lib.lib()
         alpha, w, row0, nrows = ctx.saved_tensors
         ds = torch.empty_like(alpha)
-        check(L.bmp_segsoftmax_bwd(ptr(dalpha.contiguous()), ptr(alpha), ptr(w), ptr(row0), ptr(nrows), row0.numel(),
+        dalpha = dalpha.contiguous()
+        check(L.bmp_segsoftmax_bwd(ptr(dalpha), ptr(alpha), ptr(w), ptr(row0), ptr(nrows), row0.numel(),
                                    alpha.numel(), ptr(ds), stream()), "bmp_segsoftmax_bwd")
         return ds, None, None, None
 

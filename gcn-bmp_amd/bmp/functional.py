@@ -154,6 +154,49 @@ class GRUFn(Function):
         return dh, dm, dAT, dUcT, db, None, None
 
 
+class GRUStateFn(Function):
+    """GRU update with its state apart from its input (bmp_gru_state_fwd / _bwd): what F.dropout on the step output
+    (models/ggnn.py:626-627) makes of the later calls.  WT [2d x 3d], UrzT [d x 2d], UcT [d x d], b [3d]."""
+
+    @staticmethod
+    def forward(ctx, hd, m, s, WT, UrzT, UcT, b, pb):
+        L = _lib.lib()
+        require_rows(hd, "gru: hd")
+        require_rows(m, "gru: m", hd.shape[1])
+        require_rows(s, "gru: s", hd.shape[1])
+        _check_pb(pb, hd)
+        N, d = hd.shape
+        if tuple(WT.shape) != (2 * d, 3 * d) or tuple(UrzT.shape) != (d, 2 * d) or tuple(UcT.shape) != (d, d) or tuple(b.shape) != (3 * d,):
+            raise ValueError("gru: weight shapes do not match hd")
+        WT, UrzT, UcT, b = WT.contiguous(), UrzT.contiguous(), UcT.contiguous(), b.contiguous()
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=hd.device)
+        rz, c, sout = f(N, 2 * d), f(N, d), f(N, d)
+        check(L.bmp_gru_state_fwd(ptr(hd), ptr(m), ptr(s), pb.n_tiles, d, ptr(WT), ptr(UrzT), ptr(UcT), ptr(b), ptr(rz), ptr(c),
+                                  ptr(sout), stream()), "bmp_gru_state_fwd")
+        ctx.save_for_backward(hd, m, s, WT, UrzT, UcT, rz, c)
+        ctx.pb = pb
+        return sout
+
+    @staticmethod
+    def backward(ctx, dsout):
+        L = _lib.lib()
+        hd, m, s, WT, UrzT, UcT, rz, c = ctx.saved_tensors
+        pb = ctx.pb
+        N, d = hd.shape
+        dev = hd.device
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        dhd, dm, ds = f(N, d), f(N, d), f(N, d)
+        dWT, dUrzT, dUcT, db = f(2 * d, 3 * d), f(d, 2 * d), f(d, d), f(3 * d)
+        nws = L.bmp_gru_state_bwd_ws_floats(pb.n_tiles, d)
+        ws = _ws(nws, dev)
+        dsout = dsout.contiguous()
+        A, Urz, Uc = WT.t().contiguous(), UrzT.t().contiguous(), UcT.t().contiguous()      # kept alive across the launch
+        check(L.bmp_gru_state_bwd(ptr(dsout), ptr(hd), ptr(m), ptr(s), ptr(rz), ptr(c), pb.n_tiles, d,
+                                  ptr(A), ptr(Urz), ptr(Uc), ptr(dhd), ptr(dm),
+                                  ptr(ds), ptr(dWT), ptr(dUrzT), ptr(dUcT), ptr(db), ptr(ws), nws, stream()), "bmp_gru_state_bwd")
+        return dhd, dm, ds, dWT, dUrzT, dUcT, db, None
+
+
 def step_supported(d: int) -> bool:
     return bool(_lib.lib().bmp_ggnn_step_supported(int(d)))
 

@@ -84,6 +84,14 @@ class GRU(nn.Module):
             b = torch.cat((self.W_r.b + self.U_r.b, self.W_z.b + self.U_z.b, self.W.b + self.U.b))
         return A.t().contiguous(), self.U.W.t().contiguous(), b
 
+    def kernel_weights_state(self):
+        """(WT [2d x 3d], UrzT [d x 2d], UcT [d x d], b [3d]) in the layout of bmp_gru_state_fwd: the later-call form with
+        the state terms NOT folded into the h-part (under dropout the state differs from the h half of x)."""
+        WT = torch.cat((self.W_r.W, self.W_z.W, self.W.W), dim=0).t().contiguous()
+        UrzT = torch.cat((self.U_r.W, self.U_z.W), dim=0).t().contiguous()
+        b = torch.cat((self.W_r.b + self.U_r.b, self.W_z.b + self.U_z.b, self.W.b + self.U.b))
+        return WT, UrzT, self.U.W.t().contiguous(), b
+
 
 def message_kernel_weights(lin: Linear):
     """Reference GraphLinear(d_in, 4*d_out) with output feature k = 4*c + e
@@ -260,7 +268,7 @@ class GGNN(nn.Module):
 
     # ---- layout plan protocol (bmp/plan.py): the weight-layout code above as pure functions of the parameters ----
     def plannable(self) -> bool:
-        return self.fused and not self.concat_hidden and Fn.step_supported(self.hidden_dim)
+        return self.fused and not self.concat_hidden and Fn.step_supported(self.hidden_dim) and self.dropout_rate == 0.0
 
     def _step_groups(self):
         """(message layer, GRU mode) of every step, in step order (models/ggnn.py:220, first call after reset)."""
@@ -339,13 +347,11 @@ class GGNN(nn.Module):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``
         (mb, 4, A, A), or a PackedMolBatch (then ``adj`` is ignored).  Returns (n_mols, out_dim)
         [(n_mols, n_layers*out_dim) with concat_hidden]."""
-        if self.dropout_rate != 0.0 and self.training:
-            # F.dropout after every step (models/ggnn.py:626-627) drops the step OUTPUT while the stateful GRU keeps its
-            # own un-dropped state, so the next step sees x = [dropout(h), m(dropout(h))] next to a different state s: the
-            # kernels here fold the state terms into the h-part (s == h).  Under chainer's train=False (evaluators,
-            # predict) dropout is the identity, which is what model.eval() gives.
-            raise NotImplementedError("dropout_rate != 0 is supported in eval mode only (identity, as chainer's "
-                                      "train=False); training with dropout needs a separate-state GRU kernel")
+        # F.dropout after every step (models/ggnn.py:626-627) drops the step OUTPUT while the stateful GRU keeps its own
+        # un-dropped state: later steps see x = [dropout(s), m(dropout(s))] next to the state s -- the separate-state GRU
+        # (bmp_gru_state_*); the fused kernels fold the state into the h-part and are not used then.  Under model.eval()
+        # (chainer's train=False: evaluators, predict) dropout is the identity and the usual path runs.
+        drop = self.dropout_rate != 0.0 and self.training
         dev = self.embed.W.device
         h_in = None
         if _is_float_atoms(atom_array):                                 # :604-605: float features skip the embedding
@@ -355,14 +361,16 @@ class GGNN(nn.Module):
         else:
             pb = as_packed(atom_array, adj, dev)
         fast = getattr(self, "_fast", None)
-        if fast is not None:
+        if fast is not None and not drop:
             return self._forward_fast(pb, fast, h_in)
         if h_in is None:
             pb.check_atom_ids(self.embed.W.shape[0])
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id) if h_in is None else h_in      # :603
         h0 = h                                                          # :612
         later = None
-        fused = self.fused and Fn.step_supported(self.hidden_dim)
+        fused = self.fused and Fn.step_supported(self.hidden_dim) and not drop
+        state, state_w = None, None           # dropout: the GRU's own (un-dropped) state and its unfolded weights
+        masks = getattr(self, "_dropout_masks", None)      # tests inject the masks (one (n_rows, d) tensor per step)
         g_list = []
         msgw, cache = {}, {}          # per-call: kernel-layout weights of each layer, packed copies
         for step in range(self.n_layers):                               # :616
@@ -378,6 +386,18 @@ class GGNN(nn.Module):
                 AT, UcT, b = later
             if fused:       # message + GRU in one kernel per tile, atom states resident in LDS
                 h = Fn.GGNNStepFn.apply(h, WT, bE, AT, UcT, b, pb, step == 0, cache)
+            elif drop:
+                m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
+                if state is None:
+                    state = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, True)             # first call after reset: no state yet
+                else:
+                    if state_w is None:
+                        state_w = self.update_layer.kernel_weights_state()
+                    state = Fn.GRUStateFn.apply(h, m, state, *state_w, pb)
+                if masks is not None:
+                    h = state * masks[step]
+                else:                                                              # :626-627, chainer: mask / (1 - ratio)
+                    h = torch.nn.functional.dropout(state, p=self.dropout_rate, training=True)
             else:
                 m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
                 h = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, step == 0)    # :254-262, state reset at :599

@@ -281,6 +281,106 @@ extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU update with its state APART from its input -- what dropout on the step output makes of the update
+// (models/ggnn.py:626-627: F.dropout(h) after every step, while the stateful GRU keeps the un-dropped h as its state):
+//   x = [hd, m] (hd = dropout(s)), state s:   r = sig(W_r x + U_r s + b), z = sig(W_z x + U_z s + b),
+//   c = tanh(W x + U (r*s) + b),  s' = z c + (1 - z) s.      Later calls only (the first call has no state: bmp_gru_fwd).
+// WT [2d x 3d] = [W_r | W_z | W]^T (rows [hd-part ; m-part]), UrzT [d x 2d] = [U_r | U_z]^T, UcT [d x d] = U^T,
+// b [3d] = bW + bU.  Saves rz [N x 2d] and c [N x d].
+// ---------------------------------------------------------------------------------------------
+extern "C" int bmp_gru_state_fwd(const float* hd, const float* m, const float* s, int n_tiles, int d, const float* WT,
+                                 const float* UrzT, const float* UcT, const float* b, float* rz, float* c, float* sout,
+                                 hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && d > 0 && (d & 7) == 0 && hd && m && s && WT && UrzT && UcT && b && rz && c && sout);
+    int rc;
+    {
+        RGArgs a = rg_zero();
+        a.s[0] = RGSrc{hd, nullptr, WT, d, 0, 3 * d, d};
+        a.s[1] = RGSrc{m, nullptr, WT + (size_t)d * 3 * d, d, 0, 3 * d, d};
+        a.s[2] = RGSrc{s, nullptr, UrzT, d, 0, 2 * d, d};
+        a.nsrc = 3;
+        a.Nout = 2 * d;
+        a.Y = rz; a.ldy = 2 * d;
+        a.bias = b;
+        a.act_lo = a.act_hi = BMP_ACT_SIGMOID;
+        if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
+    }
+    {
+        RGArgs a = rg_zero();
+        a.s[0] = RGSrc{hd, nullptr, WT + 2 * d, d, 0, 3 * d, d};
+        a.s[1] = RGSrc{m, nullptr, WT + (size_t)d * 3 * d + 2 * d, d, 0, 3 * d, d};
+        a.s[2] = RGSrc{rz, s, UcT, 2 * d, d, d, d};              // (r * s) . U^T
+        a.nsrc = 3;
+        a.Nout = d;
+        a.Y = sout; a.ldy = d;
+        a.bias = b + 2 * d;
+        a.z = rz + d; a.ldz = 2 * d;
+        a.h = s; a.ldh = d;
+        a.c_out = c; a.ldc = d;
+        a.first = 0;
+        if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GRU_OUT, st))) return rc;
+    }
+    return 0;
+}
+
+extern "C" size_t bmp_gru_state_bwd_ws_floats(int n_tiles, int d) { return bmp_gru_bwd_ws_floats(n_tiles, d); }
+
+// Gradients of bmp_gru_state_fwd.  A [3d x 2d] = WT^T, Urz [2d x d] = UrzT^T, Uc [d x d] = UcT^T (reference layouts).
+// Outputs: dhd, dm, ds [N x d]; dWT [2d x 3d], dUrzT [d x 2d], dUcT [d x d], db [3d].
+extern "C" int bmp_gru_state_bwd(const float* dsout, const float* hd, const float* m, const float* s, const float* rz,
+                                 const float* c, int n_tiles, int d, const float* A, const float* Urz, const float* Uc, float* dhd,
+                                 float* dm, float* ds, float* dWT, float* dUrzT, float* dUcT, float* db, float* ws,
+                                 size_t ws_floats, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && d > 0 && (d & 7) == 0 && ws_floats >= bmp_gru_state_bwd_ws_floats(n_tiles, d));
+    BMP_REQUIRE(dsout && hd && m && s && rz && c && A && Urz && Uc && dhd && dm && ds && dWT && dUrzT && dUcT && db && ws);
+    const int N = n_tiles * BMP_R;
+    float* da = ws;                              // [N x 3d]  (da_r | da_z | da_c)
+    float* dsacc = da + (size_t)N * 3 * d;       // [N x d]   direct part of ds: dsout (1 - z) + d(r*s) r
+    float* slab = dsacc + (size_t)N * d;
+    int rc;
+    hipLaunchKernelGGL(k_gru_bwd_gates, dim3(ew_blocks((size_t)N * d)), dim3(256), 0, st, dsout, s, rz, c, N, d, 0, da, dsacc);
+    BMP_LAUNCH_CHECK();
+    {   // d(r*s) = da_c . U ; da_r = d(r*s) s r (1 - r) ; dsacc += d(r*s) r
+        RGArgs a = rg_zero();
+        a.s[0] = RGSrc{da + 2 * d, nullptr, Uc, 3 * d, 0, d, d};
+        a.nsrc = 1; a.Nout = d;
+        a.Y = da; a.ldy = 3 * d;
+        a.r = rz; a.ldr = 2 * d;
+        a.h = s; a.ldh = d;
+        a.o1 = dsacc; a.ldo1 = d;
+        if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GRU_DRH, st))) return rc;
+    }
+    {   // [dhd | dm] = da . A
+        RGArgs a = rg_zero();
+        a.s[0] = RGSrc{da, nullptr, A, 3 * d, 0, 2 * d, 3 * d};
+        a.nsrc = 1; a.Nout = 2 * d;
+        a.Y = dhd; a.ldy = d;
+        a.split = d;
+        a.o1 = dm; a.ldo1 = d;
+        if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
+    }
+    {   // ds = dsacc + [da_r | da_z] . Urz
+        RGArgs a = rg_zero();
+        a.s[0] = RGSrc{da, nullptr, Urz, 3 * d, 0, d, 2 * d};
+        a.nsrc = 1; a.Nout = d;
+        a.Y = ds; a.ldy = d;
+        a.add = dsacc; a.ldadd = d;
+        if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
+    }
+    {
+        WGArgs g{hd, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dWT, 3 * d, 0};
+        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
+        WGArgs g2{m, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dWT + (size_t)d * 3 * d, 3 * d, 0};
+        if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
+        WGArgs g3{s, nullptr, d, 0, da, 3 * d, d, 2 * d, N, dUrzT, 2 * d, 0};
+        if ((rc = bmp_launch_wgrad(g3, slab, st))) return rc;
+        WGArgs g4{rz, s, 2 * d, d, da + 2 * d, 3 * d, d, d, N, dUcT, d, 0};
+        if ((rc = bmp_launch_wgrad(g4, slab, st))) return rc;
+    }
+    return bmp_launch_colsum(da, 3 * d, N, 3 * d, db, 0, slab, st);
+}
+
+// ---------------------------------------------------------------------------------------------
 // gated readout:  g[mol] = sum_rows w * sigmoid(i([h,h0])) * act_j(j([h,h0]))
 //   models/ggnn.py:333-341 (j sees h only: the caller zeroes j's h0 rows of WT)
 //   models/readout/ggnn_readout.py:42-57 (both see [h,h0], or h alone when h0 == null)

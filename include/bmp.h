@@ -79,6 +79,17 @@ int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float*
                 int first, const float* A, const float* Uc, float* dh, float* dm, float* dAT, float* dUcT, float* db,
                 float* ws, size_t ws_floats, bmp_stream_t stream);
 
+/* The same update with the GRU state apart from its input: dropout on the step output (models/ggnn.py:626-627) feeds the
+ * next step x = [hd, m] with hd = dropout(s) while the stateful GRU keeps the un-dropped s.  Later calls only (the first
+ * call after reset has no state: bmp_gru_fwd with first = 1).  WT [2d x 3d] = [W_r | W_z | W]^T (rows [hd-part; m-part]),
+ * UrzT [d x 2d] = [U_r | U_z]^T, UcT [d x d] = U^T, b [3d] = bW + bU; A, Urz, Uc: their transposes (reference layouts). */
+int bmp_gru_state_fwd(const float* hd, const float* m, const float* s, int n_tiles, int d, const float* WT, const float* UrzT,
+                      const float* UcT, const float* b, float* rz, float* c, float* sout, bmp_stream_t stream);
+size_t bmp_gru_state_bwd_ws_floats(int n_tiles, int d);
+int bmp_gru_state_bwd(const float* dsout, const float* hd, const float* m, const float* s, const float* rz, const float* c,
+                      int n_tiles, int d, const float* A, const float* Urz, const float* Uc, float* dhd, float* dm, float* ds,
+                      float* dWT, float* dUrzT, float* dUcT, float* db, float* ws, size_t ws_floats, bmp_stream_t stream);
+
 /* One whole GGNN propagation step, fused per 128-row tile -- GGNN.update models/ggnn.py:215-263
  * (message + GRU in one kernel, the tile's atom states resident in LDS).  d must satisfy
  * bmp_ggnn_step_supported(d) (64 or 128); other widths use bmp_msg_* + bmp_gru_*.

@@ -108,10 +108,11 @@ def ggnn_readout(h: Tensor, h0: Tensor, Wi: Tensor, bi: Tensor, Wj: Tensor, bj: 
 
 def ggnn_forward(p: Params, atom_array: Tensor, adj: Tensor, n_layers: int,
                  weight_tying: bool = True, concat_hidden: bool = False,
-                 prefix: str = "") -> Tuple[Tensor, Tensor]:
+                 prefix: str = "", dropout_masks: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """models/ggnn.py:584-654 / models/ggnn_att.py:589-664 default path
     (message_function='matrix_multiply', readout_function='graph_level', no
-    attention / aggregator / context / BN / dropout).
+    attention / aggregator / context / BN).  ``dropout_masks``: one (mb, atom, ch) multiplier per step in place of
+    F.dropout's random draw (:626-627).
 
     Returns (g, atoms) where atoms = h_T is what ggnn_att's get_atom_array()
     hands to the co-attention (models/ggnn_att.py:651,662-664)."""
@@ -131,6 +132,8 @@ def ggnn_forward(p: Params, atom_array: Tensor, adj: Tensor, n_layers: int,
         x = torch.cat((h.reshape(mb * atom, ch), m.reshape(mb * atom, ch)), dim=1)   # :254-260
         s = stateful_gru(sp, "update_layer", x, s)
         h = s.reshape(mb, atom, ch)                     # :262
+        if dropout_masks is not None:                   # :626-627 F.dropout(h): h * mask, mask = (rand >= ratio) / (1 - ratio);
+            h = h * dropout_masks[step]                 #          the GRU's state s stays un-dropped (stateful link)
         if concat_hidden:                               # :629-635
             g_list.append(ggnn_readout(h, h0, P(f"i_layers/{step}/W"), P(f"i_layers/{step}/b"),
                                        P(f"j_layers/{step}/W"), P(f"j_layers/{step}/b")))

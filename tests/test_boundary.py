@@ -79,7 +79,7 @@ def test_real_atom_count_ignores_weight_one_pad_rows():
     assert pb2.n_real_atoms == int(ms.n_atoms.sum())
 
 
-def test_dropout_flag_is_accepted_and_is_identity_in_eval_mode():
+def test_dropout_flag_is_accepted():
     from bmp.ggnn import GGNN
     enc = GGNN(out_dim=8, hidden_dim=16, n_layers=2, dropout_rate=0.2)      # train_ddi_modify.py:149
     assert enc.dropout_rate == 0.2

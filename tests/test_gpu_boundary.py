@@ -113,7 +113,7 @@ def test_reference_construction_forms_train_on_the_gpu():
     assert prob.shape == (6, 1) and ((prob > 0) & (prob < 1)).all()
 
 
-def test_dropout_is_identity_in_eval_mode_and_refused_in_training():
+def test_dropout_is_identity_in_eval_mode():
     from bmp import synth
     from bmp.ggnn import GGNN
     dev = torch.device("cuda:0")
@@ -126,9 +126,48 @@ def test_dropout_is_identity_in_eval_mode_and_refused_in_training():
     enc1.eval()
     with torch.no_grad():
         assert torch.equal(enc0(a, j), enc1(a, j))
-    enc1.train()
-    with pytest.raises(NotImplementedError):
-        enc1(a, j)
+
+
+@pytest.mark.parametrize("d,n_layers", [(64, 3), (128, 4)])
+def test_dropout_in_training_keeps_the_gru_state_undropped(d, n_layers):
+    """models/ggnn.py:626-627: F.dropout acts on the step output; the stateful GRU (models/ggnn.py:132) keeps its own
+    un-dropped state.  With the SAME masks on both sides (the padded positions of a molecule share a mask: they are one
+    packed row) the separate-state GRU path equals the oracle: readout, atoms, every parameter gradient."""
+    from bmp import packed, synth
+    from bmp.ggnn import GGNN
+    from bmp.snapshot import grad_dict, load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    store = synth.make_store(10, seed=21, n_lo=2, n_hi=24, n_mean=9)
+    a, j = synth.concat_mols(store)
+    mb, A = a.shape
+    p_drop = 0.25
+    p = O.make_pair_params(777, hidden_dim=d, out_dim=32, n_layers=n_layers, attn=None, dtype=torch.float64, bias_scale=0.05)
+    sub = {k[len("graph_conv/"):]: v.requires_grad_() for k, v in p.items() if k.startswith("graph_conv/")}
+    pb = packed.pack_from_dense([a], [j], device=dev)
+    rs = np.random.RandomState(3)
+    masks_rows = [T((rs.uniform(size=(pb.n_rows, d)) >= p_drop).astype(np.float64) / (1.0 - p_drop)) for _ in range(n_layers)]
+    dm = pb.dense_maps[0].cpu()
+    masks_dense = [mk[dm] for mk in masks_rows]                      # (mb, A, d): what F.dropout would have drawn
+    g_o, at_o = O.ggnn_forward(sub, T(a), T(j).double(), n_layers, True, prefix="", dropout_masks=masks_dense)
+    wv = T(rs.normal(size=tuple(g_o.shape)))
+    (g_o * wv).sum().backward()
+    enc = GGNN(out_dim=32, hidden_dim=d, n_layers=n_layers, dropout_rate=p_drop).to(dev)
+    load_param_dict(enc, {k: v.detach() for k, v in sub.items()})
+    enc.train()
+    enc._dropout_masks = [mk.float().to(dev) for mk in masks_rows]
+    g = enc(pb)
+    (g * wv.float().to(dev)).sum().backward()
+    _close(g, g_o, "g"); _close(enc.get_atom_array().dense(), at_o, "atoms")
+    for name, gr in grad_dict(enc).items():
+        _close(gr, sub[name].grad, f"grad {name}")
+    # and with its own random masks it runs and differs from the eval-mode output
+    enc._dropout_masks = None
+    g_rand = enc(pb)
+    enc.eval()
+    with torch.no_grad():
+        g_eval = enc(pb)
+    assert torch.isfinite(g_rand).all() and not torch.allclose(g_rand, g_eval)
 
 
 def test_second_backward_over_a_retained_graph_gives_the_same_weight_gradients():

@@ -408,3 +408,30 @@ def test_readout_tile_kernel_equals_gemm_plus_segment_sum(fn, batch, d, with_h0,
         if name in ("dh", "dh0"):
             a, b2 = a[rows], b2[rows]
         close(a, b2, name)
+
+
+def test_gru_with_separate_state_fwd_bwd():
+    """bmp_gru_state_fwd / _bwd (the later-call GRU with its state apart from its input: dropout on the step output,
+    models/ggnn.py:626-627) against the update rule written out in float64 (SURVEY.md A.2 with x = [hd, m], state s)."""
+    from bmp import functional as Fn, packed, synth
+    store = synth.make_store(10, seed=21, n_lo=2, n_hi=24, n_mean=9)
+    pb = packed.pack_from_store(packed.MolStore(store), [np.arange(10)], device=dev())
+    d, N = 64, pb.n_rows
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64) * 0.3
+    ref = [mk(N, d), mk(N, d), mk(N, d), mk(2 * d, 3 * d), mk(d, 2 * d), mk(d, d), mk(3 * d)]
+    cw = mk(N, d)
+    hd, m, s, WT, UrzT, UcT, b = [t.requires_grad_() for t in ref]
+    pre = torch.cat((hd, m), 1) @ WT
+    r = torch.sigmoid(pre[:, :d] + s @ UrzT[:, :d] + b[:d])
+    z = torch.sigmoid(pre[:, d:2 * d] + s @ UrzT[:, d:] + b[d:2 * d])
+    c = torch.tanh(pre[:, 2 * d:] + (r * s) @ UcT + b[2 * d:])
+    out = z * c + (1 - z) * s
+    (out * cw).sum().backward()
+    got = [t.detach().float().to(dev()).requires_grad_() for t in ref]
+    o = Fn.GRUStateFn.apply(*got, pb)
+    (o * cw.float().to(dev())).sum().backward()
+    rel = lambda a, w: ((a.double().cpu() - w).abs().max() / w.abs().max()).item()
+    assert rel(o.detach(), out.detach()) < 1e-5
+    for name, a, w in zip("hd m s WT UrzT UcT b".split(), got, ref):
+        assert rel(a.grad, w.grad) < 1e-5, name
