@@ -1009,18 +1009,38 @@ extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act
     return d == 128 ? rel_launch<128>(true, a, n_tiles, st) : rel_launch<64>(true, a, n_tiles, st);
 }
 
-extern "C" size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d) {
-    size_t a = bmp_wgrad_ws_floats(N, d, 5 * d), b = bmp_wgrad_ws_floats(N, 4, d);
-    return a > b ? a : b;
+static void rel_wgrad_problem(WGArgs* g, const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
+                              float* cs, int accumulate) {
+    g[0] = WGArgs{h, nullptr, d, 0, gda, 5 * d, d, 5 * d, N, o1, 5 * d, accumulate, cs};
+    g[0].wrow = wdeg; g[0].w_col0 = 4 * d; g[0].wout = dbE; g[0].ldwo = d;      // dbE = wdeg^T . dpre rides along
 }
 
-// Weight gradients of one layer (reduction over all N rows):
+extern "C" size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d) {
+    size_t a = bmp_wgrad_ws_floats(N, d, 5 * d), b = bmp_wgrad_ws_floats(N, 4, d);
+    a = a > b ? a : b;
+    if (step_wgrad_fusable(N, d)) {
+        WGArgs g[1];
+        rel_wgrad_problem(g, nullptr, (const float*)16, nullptr, N, d, nullptr, (float*)16, (float*)16, 0);
+        b = bmp_wgrad_fused_ws_floats(g, 1);
+        if (b > a) a = b;
+    }
+    return a;
+}
+
+// Weight gradients of one layer (reduction over all N rows), ONE GEMM launch + ONE reduction:
 //   o1 [d x 5d] = h^T . gda     cols [0,4d): dWT as [k][e*d + c];  cols [4d,5d): dWsT
-//   dbE [4 x d] = wdeg^T . dpre
+//   dbE [4 x d] = wdeg^T . dpre (weighted column sums of the dpre tile, carried by the same launch)
 //   cs [5d]     = column sums of gda; cs[4d:] = dbs
 extern "C" int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
                                       float* cs, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_relgcn_layer_wgrad_ws_floats(N, d));
+    BMP_REQUIRE(h && wdeg && gda && o1 && dbE && cs && ws);
+    static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;        // A/B switch (tools, tests)
+    if (!unfused && step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)gda & 15) == 0 && ((uintptr_t)wdeg & 15) == 0) {
+        WGArgs g[1];
+        rel_wgrad_problem(g, h, wdeg, gda, N, d, o1, dbE, cs, accumulate);
+        return bmp_launch_wgrad_fused(g, 1, ws, st, BMP_KID_WGRAD_STEP);
+    }
     int rc;
     WGArgs g1{h, nullptr, d, 0, gda, 5 * d, d, 5 * d, N, o1, 5 * d, accumulate, cs};
     if ((rc = bmp_launch_wgrad(g1, ws, st))) return rc;

@@ -416,6 +416,7 @@ struct WGKArgs {
     float* slab;
     const int* onehot;      // if set, X is not read: X[row, k] = (onehot[row] == k)  (embedding gradient as a GEMM)
     int skip_at = 0x7fffffff, skip_n = 0;     // logical column j reads dY column j + (j >= skip_at ? skip_n : 0)
+    const float* wrow = nullptr; int w_col0 = 0;      // weighted column sums (slab rows K + 1 .. K + 4) for columns >= w_col0
 };
 
 template <int MB, int NB>
@@ -531,7 +532,8 @@ __device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, in
     const int colyp = coly + (coly >= a.skip_at ? a.skip_n : 0);        // physical dY column
     const bool okx = colx < a.K, oky = coly < a.Nn;
     const bool do_cs = want_cs && bx == 0;
-    const int Krows = a.K + (want_cs ? 1 : 0);
+    const bool do_w = do_cs && a.wrow != nullptr && j_tile >= a.w_col0;
+    const int Krows = a.K + (want_cs ? 1 : 0) + (a.wrow ? 4 : 0);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -541,7 +543,8 @@ __device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, in
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
     f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 xr[4], yr[4];
+    f32x4 csw[4] = {csum, csum, csum, csum};
+    f32x4 xr[4], yr[4], wr4[4];
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #define WG_LOAD(st)                                                                                  \
@@ -555,12 +558,14 @@ __device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, in
             if (HAS_X2 && okx) xr[i] *= *(const f32x4*)(a.X2 + row * a.ldx2 + colx);                 \
         }                                                                                            \
         yr[i] = oky ? *(const f32x4*)(a.dY + row * a.ldy + colyp) : zero4;                            \
+        if (do_w) wr4[i] = *(const f32x4*)(a.wrow + row * 4);                                        \
     }
 #define WG_STORE(buf)                                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
         *(f32x4*)(&XS[buf][rr + 8 * i][4 * c4]) = xr[i];                                             \
         *(f32x4*)(&YS[buf][rr + 8 * i][4 * c4]) = yr[i];                                             \
         csum += yr[i];                                                                               \
+        if (do_w) { _Pragma("unroll") for (int e = 0; e < 4; ++e) csw[e] += wr4[i][e] * yr[i]; }     \
     }
 
     if (nst > 0) {
@@ -624,6 +629,20 @@ __device__ __forceinline__ void wgrad_lds_body(const WGKArgs& a, int want_cs, in
             for (int g = 1; g < 8; ++g) t += red[g * 32 + c4];
             *(f32x4*)(slab + (size_t)a.K * a.Nn + coly) = t;
         }
+        if (do_w) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __syncthreads();
+                red[rr * 32 + c4] = csw[e];
+                __syncthreads();
+                if (rr == 0 && oky) {
+                    f32x4 t = red[c4];
+#pragma unroll
+                    for (int g = 1; g < 8; ++g) t += red[g * 32 + c4];
+                    *(f32x4*)(slab + (size_t)(a.K + 1 + e) * a.Nn + coly) = t;
+                }
+            }
+        }
     }
 }
 
@@ -658,6 +677,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
 struct RedProb {
     const float* slab; int S, K, Krows, Nn, Nn_phys, skip_at, skip_n;
     float* out; int ldo, accumulate; float* cs_out; int cs_accumulate;
+    float* wout; int ldwo, w_col0;          // rows K + 1 .. K + 4: weighted column sums of the columns >= w_col0
 };
 struct RedMulti { RedProb p[3]; int b0[4]; };
 __global__ __launch_bounds__(256) void k_reduce_multi(RedMulti m) {
@@ -675,7 +695,7 @@ __global__ __launch_bounds__(256) void k_reduce_multi(RedMulti m) {
         const bool skipped = jp >= q.skip_at && jp < q.skip_at + q.skip_n;
         const int jl = jp - (jp >= q.skip_at + q.skip_n ? q.skip_n : 0);
         float v = 0.f;
-        if (idx < total && !skipped) {
+        if (idx < total && !skipped && !(i > q.K && jp < q.w_col0)) {
 #pragma unroll 8
             for (int s = g; s < q.S; s += 4) v += q.slab[(size_t)s * slab_sz + (size_t)i * q.Nn + jl];
         }
@@ -683,9 +703,16 @@ __global__ __launch_bounds__(256) void k_reduce_multi(RedMulti m) {
         __syncthreads();
         if (g == 0 && idx < total) {
             v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-            const bool is_cs = i == q.K;
-            float* o = is_cs ? (q.cs_out + jp) : (q.out + (size_t)i * q.ldo + jp);
-            *o = (is_cs ? q.cs_accumulate : q.accumulate) ? (*o + v) : v;
+            if (i > q.K) {
+                if (jp >= q.w_col0) {
+                    float* o = q.wout + (size_t)(i - q.K - 1) * q.ldwo + (jp - q.w_col0);
+                    *o = q.accumulate ? (*o + v) : v;
+                }
+            } else {
+                const bool is_cs = i == q.K;
+                float* o = is_cs ? (q.cs_out + jp) : (q.out + (size_t)i * q.ldo + jp);
+                *o = (is_cs ? q.cs_accumulate : q.accumulate) ? (*o + v) : v;
+            }
         }
         __syncthreads();
     }
@@ -868,7 +895,7 @@ size_t bmp_wgrad_fused_ws_floats(const WGArgs* a, int n) {
     int S[3], rps[3], ty0[4];
     wgrad_fused_plan(a, n, S, rps, ty0);
     size_t tot = 0;
-    for (int p = 0; p < n; ++p) tot += (size_t)S[p] * (a[p].K + 1) * a[p].Nn;
+    for (int p = 0; p < n; ++p) tot += (size_t)S[p] * (a[p].K + 5) * a[p].Nn;
     return tot;
 }
 
@@ -881,6 +908,7 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
         BMP_REQUIRE(a[p].K <= 128 && !a[p].onehot && (a[p].zero_only || wgrad_use_lds(a[p])));
         BMP_REQUIRE(a[p].skip_n == 0 || ((a[p].skip_at & 127) == 0 && (a[p].skip_n & 3) == 0));
         BMP_REQUIRE(a[p].N == a[0].N);
+        BMP_REQUIRE(!a[p].wrow || (a[p].cs && a[p].wout && a[p].skip_n == 0 && (a[p].w_col0 & 127) == 0));
     }
     wgrad_fused_plan(a, n, m.S, rps, m.ty0);
     size_t off = 0;
@@ -893,7 +921,11 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
         k.skip_at = a[p].skip_at; k.skip_n = a[p].skip_n;
         m.p[p] = k;
         RedProb& q = r.p[p];
-        q.slab = ws + off; q.S = m.S[p]; q.K = a[p].K; q.Krows = a[p].K + want_cs; q.Nn = a[p].Nn;
+        const int nw = (a[p].wrow && want_cs) ? 4 : 0;
+        k.wrow = nw ? a[p].wrow : nullptr; k.w_col0 = a[p].w_col0;
+        m.p[p] = k;
+        q.slab = ws + off; q.S = m.S[p]; q.K = a[p].K; q.Krows = a[p].K + want_cs + nw; q.Nn = a[p].Nn;
+        q.wout = a[p].wout; q.ldwo = a[p].ldwo; q.w_col0 = a[p].w_col0;
         q.Nn_phys = a[p].Nn + a[p].skip_n; q.skip_at = a[p].skip_n ? a[p].skip_at : 0x7fffffff; q.skip_n = a[p].skip_n;
         q.out = a[p].out; q.ldo = a[p].ldo; q.accumulate = a[p].accumulate; q.cs_out = a[p].cs;
         q.cs_accumulate = a[p].accumulate | a[p].cs_accumulate;

@@ -67,6 +67,9 @@ struct WGArgs {
     // are written as zeros unless accumulating); zero_only: no product at all, out is zero-filled unless accumulating
     int skip_at = 0x7fffffff, skip_n = 0;
     int zero_only = 0;
+    // ... and weighted column sums riding along: wout[e, j - w_col0] (=|+=) sum_rows wrow[row, e] * dY[row, j] for the
+    // logical columns j >= w_col0 (e < 4; wrow [N x 4]): the per-bond-type bias gradient of a RelGCN layer
+    const float* wrow = nullptr; int w_col0 = 0; float* wout = nullptr; int ldwo = 0;
 };
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
