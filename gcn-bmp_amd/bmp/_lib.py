@@ -12,7 +12,7 @@ from ctypes import c_float, c_int, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbmp_hip.so")
+LIB_PATH = os.environ.get("BMP_LIB_PATH") or os.path.join(_HERE, "libbmp_hip.so")      # BMP_LIB_PATH: A/B builds (tools)
 
 _P, _I, _Z, _F = c_void_p, c_int, c_size_t, c_float
 

@@ -86,6 +86,10 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
         int col = n0 + (wc * CBW + cb) * 32 + l31;
         colc[cb] = col < a.Nout ? col : a.Nout - 1;     // clamp loads, mask stores
     }
+    // a wave whose 32-column blocks all lie beyond Nout (the remainder tile of e.g. 144 columns keeps one wave of four
+    // busy) stages rows and meets the barriers but issues no weight loads and no MFMAs: the matrix pipe of its SIMD is
+    // left to the workgroups that share the CU
+    const bool wave_active = n0 + wc * CBW * 32 < a.Nout;
 
     // The K axis of all sources as one sequence of <= 64-wide chunks.  The rows of chunk i+1 are requested into
     // registers before the MFMAs of chunk i (they used to be loaded, waited for and stored between two barriers
@@ -135,6 +139,7 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
             // of step s issue; scheduling barriers keep the compiler from sinking the loads behind them
             f32x4 a0[RB], a1[RB];
             float b0[CBW][4], b1[CBW][4];
+            if (wave_active) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) a0[rb] = *(const f32x4*)(&lds[((wr * RB + rb) * 32 + l31) * BMP_LDS_LD + 4 * hi]);
 #pragma unroll
@@ -166,6 +171,7 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
 #pragma unroll
                     for (int t = 0; t < 4; ++t) b0[cb][t] = b1[cb][t];
             }
+            }   // wave_active
             if (more) {
                 __syncthreads();               // every wave is done with the chunk in LDS
                 store_chunk();
@@ -174,6 +180,7 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
         }
     }
 
+    if (wave_active)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
