@@ -13,3 +13,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 python tools/summarize_pmc.py gpurun_out/r02_c2_pmc_sq.json gpurun_out/pmc_s > /dev/null
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s
 ls gpurun_out | grep r02_
+for c in c2 c3 c4; do
+  python bench.py --config $c > gpurun_out/r02_bench_$c.json 2> gpurun_out/r02_bench_$c.err
+done
+ls gpurun_out | grep r02_bench
