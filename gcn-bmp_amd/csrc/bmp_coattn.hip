@@ -128,6 +128,45 @@ __device__ __forceinline__ void co_stats(const CoLds& L, int n1, int n2, int ldc
     }
 }
 
+// The same statistics with Q lanes per atom (Q a power of two <= 16, adjacent lanes): lane q walks the other side's
+// atoms q, q + Q, ...; maxima and sums meet through shuffles inside the lane group.  A pair of two 28-atom molecules keeps
+// 448 of 512 threads busy instead of 56 (one thread per atom walked 28 exponentials twice, the rest waited at the barrier).
+__device__ __forceinline__ float grp_max(float v, int Q) {
+    for (int m = Q >> 1; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float grp_sum(float v, int Q) {
+    for (int m = Q >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int co_split(int n1, int n2, int nt) {
+    int Q = 1;
+    while (Q < 16 && 2 * Q * (n1 + n2) <= nt) Q *= 2;
+    return Q;
+}
+__device__ __forceinline__ void co_stats_split(const CoLds& L, int n1, int n2, int ldc, int Q) {
+    const int a = threadIdx.x / Q, q = threadIdx.x % Q;
+    if (a < n1) {
+        const int j = a;
+        float mx = -INFINITY;
+        for (int i = q; i < n2; i += Q) if (L.w2s[i] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
+        mx = grp_max(mx, Q);
+        float s = 0.f;
+        for (int i = q; i < n2; i += Q) if (L.w2s[i] > 0.f) s += L.w2s[i] * bmp_exp(L.Cs[i * ldc + j] - mx);
+        s = grp_sum(s, Q);
+        if (q == 0) { L.cmax[j] = mx; L.invD2[j] = 1.f / s; }
+    } else if (a < n1 + n2) {
+        const int i = a - n1;
+        float mx = -INFINITY;
+        for (int j = q; j < n1; j += Q) if (L.w1s[j] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
+        mx = grp_max(mx, Q);
+        float s = 0.f;
+        for (int j = q; j < n1; j += Q) if (L.w1s[j] > 0.f) s += L.w1s[j] * bmp_exp(L.Cs[i * ldc + j] - mx);
+        s = grp_sum(s, Q);
+        if (q == 0) { L.rmax[i] = mx; L.invD1[i] = 1.f / s; }
+    }
+}
+
 // L2[i,j] (softmax over i) and L1[j,i] (softmax over j); zero-weight rows get weight 0 in every sum,
 // so their (possibly huge) exponent is never used.
 __device__ __forceinline__ float co_L2(const CoLds& L, int i, int j, int ldc) {
@@ -211,7 +250,9 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
             }
         }
     } else {
-    co_stats(L, n1, n2, ldc);
+    const int Q = co_split(n1, n2, NT);
+    co_stats_split(L, n1, n2, ldc, Q);
+    __syncthreads();
     {   // the backward reloads these instead of walking C again (17 % of its time): kept behind the pair's C block
         float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
         if (tid < CO_MAXN) { if (tid < n1) { st[tid] = L.cmax[tid]; st[n1 + tid] = L.invD2[tid]; } }
@@ -219,46 +260,38 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     }
     __syncthreads();
 
-    // ---- head projections: H1 = tanh(P1 + L1 . P2), H2 = tanh(P2 + L2 . P1)  (:352-362) ----
-    if (tid < CO_MAXN) {
-        const int j = tid;
-        if (j < n1) {
-            float acc[HN];
+    // ---- head projections: H1 = tanh(P1 + L1 . P2), H2 = tanh(P2 + L2 . P1)  (:352-362), Q lanes per atom ----
+    {
+        const int a_ = tid / Q, q = tid % Q;
+        const bool side1 = a_ < n1, valid = a_ < n1 + n2;
+        const int me = side1 ? a_ : a_ - n1;
+        const int no = side1 ? n2 : n1;
+        const float* Po = side1 ? L.P2s : L.P1s;
+        const float* wo = side1 ? L.w2s : L.w1s;
+        float acc[HN];
 #pragma unroll
-            for (int h = 0; h < HN; ++h) acc[h] = 0.f;
-            for (int i = 0; i < n2; ++i) {
-                const float e = L.w2s[i] * co_L1(L, i, j, ldc);
+        for (int h = 0; h < HN; ++h) acc[h] = 0.f;
+        if (valid) {
+            for (int k = q; k < no; k += Q) {
+                const float e = wo[k] * (side1 ? co_L1(L, k, me, ldc) : co_L2(L, me, k, ldc));
 #pragma unroll
-                for (int h = 0; h < HN; ++h) if (h < H) acc[h] += e * L.P2s[i * H + h];
+                for (int h = 0; h < HN; ++h) if (h < H) acc[h] += e * Po[k * H + h];
             }
-            float s = 0.f;
-#pragma unroll
-            for (int h = 0; h < HN; ++h) if (h < H) {
-                const float hv = bmp_tanh(L.P1s[j * H + h] + acc[h]);
-                a.H1[(size_t)(r1 + j) * H + h] = hv;
-                s += hv * a.wa1[h];
-            }
-            L.s1[j] = s;
         }
-    } else {
-        const int i = tid - CO_MAXN;
-        if (i < n2) {
-            float acc[HN];
 #pragma unroll
-            for (int h = 0; h < HN; ++h) acc[h] = 0.f;
-            for (int j = 0; j < n1; ++j) {
-                const float e = L.w1s[j] * co_L2(L, i, j, ldc);
-#pragma unroll
-                for (int h = 0; h < HN; ++h) if (h < H) acc[h] += e * L.P1s[j * H + h];
-            }
-            float s = 0.f;
+        for (int h = 0; h < HN; ++h) if (h < H) acc[h] = grp_sum(acc[h], Q);
+        if (valid && q == 0) {
+            const float* Pm = side1 ? L.P1s : L.P2s;
+            const float* wa = side1 ? a.wa1 : a.wa2;
+            float* Hg = side1 ? a.H1 + (size_t)(r1 + me) * H : a.H2 + (size_t)(r2 + me) * H;
+            float sc = 0.f;
 #pragma unroll
             for (int h = 0; h < HN; ++h) if (h < H) {
-                const float hv = bmp_tanh(L.P2s[i * H + h] + acc[h]);
-                a.H2[(size_t)(r2 + i) * H + h] = hv;
-                s += hv * a.wa2[h];
+                const float hv = bmp_tanh(Pm[me * H + h] + acc[h]);
+                Hg[h] = hv;
+                sc += hv * wa[h];
             }
-            L.s2[i] = s;
+            (side1 ? L.s1 : L.s2)[me] = sc;
         }
     }
     }   // mode
