@@ -170,9 +170,8 @@ extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ld
         if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
     }
     if (Ws) {
-        WGArgs g{x, nullptr, ldx, 0, dpre, lddp, d_in, d_out, N, dWsT, d_out, 0};
+        WGArgs g{x, nullptr, ldx, 0, dpre, lddp, d_in, d_out, N, dWsT, d_out, 0, dbs};      // + dbs = column sums of dpre
         if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
-        if ((rc = bmp_launch_colsum(dpre, lddp, N, d_out, dbs, 0, slab, st))) return rc;
     }
     return 0;
 }
@@ -265,7 +264,8 @@ extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, c
         if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
     }
     {   // dAT rows 0..d-1 = h^T . da ; rows d..2d-1 = m^T . da
-        WGArgs g{h, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT, 3 * d, 0};
+        // db = column sums of da: carried by the first GEMM (it reads da anyway; a pass of its own re-read N x 3d floats)
+        WGArgs g{h, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT, 3 * d, 0, db};
         if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
         WGArgs g2{m, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT + (size_t)d * 3 * d, 3 * d, 0};
         if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
@@ -277,7 +277,7 @@ extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, c
         hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    return bmp_launch_colsum(da, 3 * d, N, 3 * d, db, 0, slab, st);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,7 +368,7 @@ extern "C" int bmp_gru_state_bwd(const float* dsout, const float* hd, const floa
         if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
     }
     {
-        WGArgs g{hd, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dWT, 3 * d, 0};
+        WGArgs g{hd, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dWT, 3 * d, 0, db};       // + db = column sums of da
         if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
         WGArgs g2{m, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dWT + (size_t)d * 3 * d, 3 * d, 0};
         if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
@@ -377,7 +377,7 @@ extern "C" int bmp_gru_state_bwd(const float* dsout, const float* hd, const floa
         WGArgs g4{rz, s, 2 * d, d, da + 2 * d, 3 * d, d, d, N, dUcT, d, 0};
         if ((rc = bmp_launch_wgrad(g4, slab, st))) return rc;
     }
-    return bmp_launch_colsum(da, 3 * d, N, 3 * d, db, 0, slab, st);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,14 +442,13 @@ extern "C" int bmp_readout_bwd(const float* dg, const float* h, const float* h0,
         if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
     }
     {
-        WGArgs g{h, nullptr, d, 0, dij, 2 * o, d, 2 * o, N, dWT, 2 * o, 0};
+        WGArgs g{h, nullptr, d, 0, dij, 2 * o, d, 2 * o, N, dWT, 2 * o, 0, db};            // + db = column sums of dij (db may be null)
         if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
         if (h0) {
             WGArgs g2{h0, nullptr, d0, 0, dij, 2 * o, d0, 2 * o, N, dWT + (size_t)d * 2 * o, 2 * o, 0};
             if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
         }
     }
-    if (db) return bmp_launch_colsum(dij, 2 * o, N, 2 * o, db, 0, slab, st);
     return 0;
 }
 
