@@ -547,6 +547,46 @@ class PReadoutFn(Function):
         return dh, dh0, None, None, None, None, None
 
 
+class PGRUFn(Function):
+    """GRUFn on prepared weights (bmp/plan.py), for the widths the fused step kernels do not cover.
+    W: AT, UcT, b, A (= AT^T), Uc (= UcT^T); G: dAT, dUcT, db of the GRU mode's group."""
+
+    @staticmethod
+    def forward(ctx, h, m, pb, W, G, state, gkey, first):
+        L = _lib.lib()
+        require_rows(h, "gru: h")
+        require_rows(m, "gru: m", h.shape[1])
+        _check_pb(pb, h)
+        N, d = h.shape
+        f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=h.device)
+        rz, c, hout = f(N, 2 * d), f(N, d), f(N, d)
+        check(L.bmp_gru_fwd(ptr(h), ptr(m), pb.n_tiles, d, int(first), ptr(W["AT"]), ptr(W["UcT"]), ptr(W["b"]), ptr(rz), ptr(c),
+                            ptr(hout), stream()), "bmp_gru_fwd")
+        ctx.save_for_backward(h, m, rz, c)
+        ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
+        _register(state, gkey)
+        return hout
+
+    @staticmethod
+    def backward(ctx, dhout):
+        L = _lib.lib()
+        h, m, rz, c = ctx.saved_tensors
+        pb, W, G = ctx.pb, ctx.W, ctx.G
+        N, d = h.shape
+        dhout = dhout.contiguous()
+        dh, dm = torch.empty_like(h), torch.empty_like(m)
+        first_w = _first_write(ctx.state, ctx.gkey)
+        T = G if first_w else {k: torch.empty_like(v) for k, v in G.items()}
+        nws = L.bmp_gru_bwd_ws_floats(pb.n_tiles, d)
+        ws = _ws(nws, h.device)
+        check(L.bmp_gru_bwd(ptr(dhout), ptr(h), ptr(m), ptr(rz), ptr(c), pb.n_tiles, d, ctx.first, ptr(W["A"]), ptr(W["Uc"]),
+                            ptr(dh), ptr(dm), ptr(T["dAT"]), ptr(T["dUcT"]), ptr(T["db"]), ptr(ws), nws, stream()), "bmp_gru_bwd")
+        if not first_w:
+            for k in G:
+                G[k].add_(T[k])
+        return dh, dm, None, None, None, None, None, None
+
+
 class PMsgFn(Function):
     """MsgFn (message / RelGCN layer) on prepared weights.  W: WT, bE, WsT, bs, Wnat, Ws; G: dWT, dbE, dWsT, dbs."""
 

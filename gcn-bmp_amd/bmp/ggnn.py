@@ -268,7 +268,11 @@ class GGNN(nn.Module):
 
     # ---- layout plan protocol (bmp/plan.py): the weight-layout code above as pure functions of the parameters ----
     def plannable(self) -> bool:
-        return self.fused and not self.concat_hidden and Fn.step_supported(self.hidden_dim) and self.dropout_rate == 0.0
+        return self.fused and not self.concat_hidden and self.dropout_rate == 0.0
+
+    def _plan_fused(self) -> bool:
+        """The plan's arrays are those of the fused step kernels (d = 64 / 128) or of the unfused operators (other widths)."""
+        return Fn.step_supported(self.hidden_dim)
 
     def _step_groups(self):
         """(message layer, GRU mode) of every step, in step order (models/ggnn.py:220, first call after reset)."""
@@ -286,6 +290,16 @@ class GGNN(nn.Module):
 
     def prepared_layouts(self):
         p = self.primary_layouts()
+        if not self._plan_fused():          # unfused operators: K-major operands and their transposes, nothing packed
+            out = {"embed.W": p["embed.W"], "gru.UcT": p["gru.UcT"], "gru.Uc": p["gru.UcT"].t().contiguous(),
+                   "ro.WT": p["ro.WT"], "ro.b": p["ro.b"], "ro.Wnat": p["ro.WT"].t().contiguous()}
+            for li in range(self.n_message_layer):
+                out[f"msg{li}.WT"], out[f"msg{li}.bE"] = p[f"msg{li}.WT"], p[f"msg{li}.bE"]
+                out[f"msg{li}.Wnat"] = p[f"msg{li}.WT"].t().contiguous()
+            for mode in ("first", "later"):
+                out[f"gru_{mode}.AT"], out[f"gru_{mode}.b"] = p[f"gru_{mode}.AT"], p[f"gru_{mode}.b"]
+                out[f"gru_{mode}.A"] = p[f"gru_{mode}.AT"].t().contiguous()
+            return out
         out = {"embed.W": p["embed.W"], "gru.UcTp": Fn.pack_k4(p["gru.UcT"]), "gru.Uc_p": Fn.pack_k4(p["gru.UcT"].t()),
                "ro.WT": p["ro.WT"], "ro.b": p["ro.b"], "ro.Wnat": p["ro.WT"].t().contiguous()}
         if p["ro.WT"].shape[0] % 4 == 0:
@@ -301,6 +315,12 @@ class GGNN(nn.Module):
     def gk_spec(self):
         d, o = self.hidden_dim, self.out_dim
         spec = {"embed.dW": tuple(self.embed.W.shape), "ro.dWT": (2 * d, 2 * o), "ro.db": (2 * o,)}
+        if not self._plan_fused():
+            for li in range(self.n_message_layer):
+                spec[f"msg{li}.dWT"], spec[f"msg{li}.dbE"] = (4 * d, d), (4, d)
+            for mode in dict.fromkeys(m for _l, m in self._step_groups()):
+                spec[f"gru_{mode}.dAT"], spec[f"gru_{mode}.dUcT"], spec[f"gru_{mode}.db"] = (2 * d, 3 * d), (d, d), (3 * d,)
+            return spec
         for li, mode in dict.fromkeys(self._step_groups()):
             for k, shp in (("o1", (d, 7 * d)), ("o2", (d, 3 * d)), ("dUcT", (d, d)), ("cs", (7 * d,))):
                 spec[f"g{li}_{mode}.{k}"] = shp
@@ -311,6 +331,16 @@ class GGNN(nn.Module):
         GGNNStepFn.backward does)."""
         d = self.hidden_dim
         groups = list(dict.fromkeys(self._step_groups()))
+        if not self._plan_fused():
+            modes = list(dict.fromkeys(m for _l, m in groups))
+            out = {"embed.W": [gk["embed.dW"]], "ro.WT": [gk["ro.dWT"]], "ro.b": [gk["ro.db"]],
+                   "gru.UcT": [gk[f"gru_{m}.dUcT"] for m in modes if m == "later"]}
+            for li in range(self.n_message_layer):
+                out[f"msg{li}.WT"], out[f"msg{li}.bE"] = [gk[f"msg{li}.dWT"]], [gk[f"msg{li}.dbE"]]
+            for mode in ("first", "later"):
+                out[f"gru_{mode}.AT"] = [gk[f"gru_{mode}.dAT"]] if mode in modes else []
+                out[f"gru_{mode}.b"] = [gk[f"gru_{mode}.db"]] if mode in modes else []
+            return out
         out = {"embed.W": [gk["embed.dW"]], "ro.WT": [gk["ro.dWT"]], "ro.b": [gk["ro.db"]],
                "gru.UcT": [gk[f"g{li}_{mode}.dUcT"] for li, mode in groups if mode == "later"]}
         for li in range(self.n_message_layer):
@@ -333,6 +363,16 @@ class GGNN(nn.Module):
         else:
             h = h_in
         h0 = h
+        if not self._plan_fused():
+            for step, (li, mode) in enumerate(self._step_groups()):
+                Wm = dict(WT=P[f"msg{li}.WT"], bE=P[f"msg{li}.bE"], Wnat=P[f"msg{li}.Wnat"])
+                m = Fn.PMsgFn.apply(h, pb, Wm, dict(dWT=G[f"msg{li}.dWT"], dbE=G[f"msg{li}.dbE"]), state, f"msg{li}", Fn.ACT["identity"])
+                Wg = dict(AT=P[f"gru_{mode}.AT"], UcT=P["gru.UcT"], b=P[f"gru_{mode}.b"], A=P[f"gru_{mode}.A"], Uc=P["gru.Uc"])
+                Gg = dict(dAT=G[f"gru_{mode}.dAT"], dUcT=G[f"gru_{mode}.dUcT"], db=G[f"gru_{mode}.db"])
+                h = Fn.PGRUFn.apply(h, m, pb, Wg, Gg, state, f"gru_{mode}", step == 0)
+            self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
+            return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
+                                       dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state)
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
                      b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])

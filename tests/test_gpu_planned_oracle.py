@@ -84,6 +84,44 @@ def test_planned_training_step_matches_oracle_at_d128(encoder, n_layers):
         off += n
 
 
+def test_planned_c4_step_matches_oracle_at_d256():
+    """Config C4's model (GGNN d = 256, no co-attention, 37 multi-hot classes, train_ggnn_hole_multi_class_x37.py:71-91) on the
+    planned path of the UNFUSED operators (the widths the fused step kernels do not cover: PMsgFn / PGRUFn on prepared
+    weights): logits, loss and the flat gradient against the oracle."""
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    store = synth.make_store(40, seed=4, n_lo=3, n_hi=36, n_mean=14)
+    ms = packed.MolStore(store)
+    rs = np.random.RandomState(2)
+    B, C = 10, 37
+    i1, i2 = rs.randint(0, 40, B), rs.randint(0, 40, B)
+    lab = (rs.uniform(size=(B, C)) < 0.08).astype(np.int32)
+    lab[1, 5] = -1
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    p = O.make_pair_params(777, hidden_dim=256, out_dim=256, n_layers=4, attn=None, class_num=C, dtype=torch.float64, bias_scale=0.05)
+    y_o, loss_o, g_o, _ = _oracle_step(p, (a1, j1, a2, j2, lab), "ggnn", 4, None, 1e-3)
+    model = build_pair_predictor(hidden_dim=256, out_dim=256, n_layers=4, attn=None, class_num=C).to(dev)
+    load_param_dict(model, p)
+    opt = FlatAdam(model, alpha=1e-3)
+    pb, t = packed.pack_from_store_device(packed.DeviceMolStore(ms, dev), [i1, i2], labels=lab)
+    for _ in range(2):                                   # twice: nothing stale may survive from the step before
+        y = opt.functional_forward(pb)
+        assert opt.plan is not None and "graph_conv." in opt.plan.P and "msg0.WT" in opt.plan.P["graph_conv."]
+        loss = model.loss(y, t)
+        loss.backward()
+        opt.collect_grads()
+        _close(y, y_o, "logits"); _close(loss, loss_o, "loss")
+        off = 0
+        for name, shp in zip(opt.names, opt.shapes):
+            n = int(np.prod(shp))
+            _close(opt.grad[off:off + n].view(shp), g_o[name.replace(".", "/")], f"grad {name}")
+            off += n
+
+
 def test_c3_composed_matches_dense_oracle_eager_at_d128():
     """build_pair_predictor(encoder='relgcn', hidden_dim=128, n_layers=3, attn='nie') (models/relgcn.py:61-73 +
     nie_coattention.py:335-370), module call (eager path): logits, loss and every parameter gradient."""
