@@ -315,6 +315,127 @@ __device__ __forceinline__ void rowgemm_lds_body(const RGArgs& a, int bx, int by
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 128 x 128 tile with both operands DOUBLE-buffered in LDS in 32-deep K chunks: chunk c + 1 is requested into
+// registers at the top of chunk c and written to the other buffer after its MFMAs -- one barrier per chunk instead of a
+// store between two barriers with the matrix pipe idle; the weights sit in LDS as [k/4][column][4] (16-byte slot of column
+// n at n ^ ((n >> 4) & 3): the register-transposing store and the fragment reads are both bank-conflict free), so a
+// lane's four consecutive k of its column are ONE ds_read_b128 (the form above reads four ds_read_b32).  Same LDS
+// footprint (two workgroups per CU), same epilogue.
+// ---------------------------------------------------------------------------------------------
+#define RGD_LDA 36
+#define RGD_A_FLOATS (128 * RGD_LDA)
+#define RGD_B_FLOATS (8 * 128 * 4)
+#define RGD_SWZ(n) ((n) ^ (((n) >> 4) & 3))
+template <int EPI>
+__device__ __forceinline__ void rowgemm_db_body(const RGArgs& a, int bx, int by, float* lds) {
+    constexpr int RB = 4, R = 128, NT = 128;
+    constexpr int BUF = RGD_A_FLOATS + RGD_B_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int row0 = bx * R, n0 = by * NT;
+
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+
+    f32x4 sa[4], sb[4];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bk4 = tid >> 5, bnq = tid & 31;                  // weight item of this thread: k rows 4 bk4 .. +3, columns 4 bnq .. +3
+    auto load_chunk = [&](int s_, int k0_) {
+        const float* __restrict__ X = a.s[s_].X;
+        const float* __restrict__ X2 = a.s[s_].X2;
+        const float* __restrict__ Wt = a.s[s_].Wt;
+        const int ldx = a.s[s_].ldx, ldx2 = a.s[s_].ldx2, ldw = a.s[s_].ldw, K = a.s[s_].K;
+        const int kc = (K - k0_) < 32 ? (K - k0_) : 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256;
+            const int r = idx >> 3, c4 = idx & 7;
+            f32x4 v = zero4;
+            if (4 * c4 < kc) {
+                v = *(const f32x4*)(X + (size_t)(row0 + r) * ldx + k0_ + 4 * c4);
+                if (X2) v *= *(const f32x4*)(X2 + (size_t)(row0 + r) * ldx2 + k0_ + 4 * c4);
+            }
+            sa[it] = v;
+        }
+        const int col = n0 + 4 * bnq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = 4 * bk4 + t;
+            sb[t] = (k < kc && col < a.Nout) ? *(const f32x4*)(Wt + (size_t)(k0_ + k) * ldw + col) : zero4;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256;
+            *(f32x4*)(&lds[buf * BUF + (idx >> 3) * RGD_LDA + 4 * (idx & 7)]) = sa[it];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)                           // 4 x 4 transpose in registers: [k][n] -> [n][k]
+            *(f32x4*)(&lds[buf * BUF + RGD_A_FLOATS + (bk4 * 128 + RGD_SWZ(4 * bnq + jj)) * 4]) =
+                (f32x4){sb[0][jj], sb[1][jj], sb[2][jj], sb[3][jj]};
+    };
+    int nchunks = 0;
+    for (int s = 0; s < a.nsrc; ++s) nchunks += (a.s[s].K + 31) >> 5;
+    int cs = 0, ck0 = 0;
+    auto advance = [&]() { ck0 += 32; if (ck0 >= a.s[cs].K) { ++cs; ck0 = 0; } };
+    load_chunk(cs, ck0); advance();
+    store_chunk(0);
+    __syncthreads();
+    const int bslot = RGD_SWZ(wc * 32 + l31);
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nchunks;
+        if (more) { load_chunk(cs, ck0); advance(); }
+        const float* la = lds + buf * BUF + l31 * RGD_LDA + 4 * hi;
+        const float* lb = lds + buf * BUF + RGD_A_FLOATS + ((size_t)hi * 128 + bslot) * 4;
+        f32x4 a0[RB], a1[RB], b0, b1;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a0[rb] = *(const f32x4*)(la + rb * 32 * RGD_LDA);
+        b0 = *(const f32x4*)lb;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 8) {
+            if (kk + 8 < 32) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a1[rb] = *(const f32x4*)(la + rb * 32 * RGD_LDA + kk + 8);
+                b1 = *(const f32x4*)(lb + (size_t)((kk + 8) >> 2) * 128 * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = bmp_mfma(a0[rb][t], b0[t], acc[rb]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a0[rb] = a1[rb];
+            b0 = b1;
+        }
+        if (more) store_chunk(buf ^ 1);        // the other buffer: last read in chunk c - 1, every wave is past that barrier
+        __syncthreads();
+    }
+    const int col = n0 + wc * 32 + l31;
+    if (col < a.Nout) {
+        const RGCol cc = rg_col(a, col);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + rb * 32 + bmp_acc_row(reg, lane);
+                rg_epilogue<EPI>(a, cc, row, col, acc[rb][reg]);
+            }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_rowgemm_db(RGArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (RGD_A_FLOATS + RGD_B_FLOATS)];
+    rowgemm_db_body<EPI>(a, blockIdx.x, blockIdx.y, lds);      // (column tiles fastest in the grid: 1.5 % slower on C4)
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm_lds(RGArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[128 * BMP_LDS_LD + 64 * RGB_LDB];
@@ -357,7 +478,9 @@ static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
         const int ny = (a.Nout + 127) / 128;
         // problems that do not even give every CU one 128-row workgroup take 64-row workgroups: the launch is one
         // round either way, and its duration is one workgroup's latency
+        static const int form = getenv("BMP_ROWGEMM_FORM") ? atoi(getenv("BMP_ROWGEMM_FORM")) : 0;    // 1: single-buffered form
         if (n_tiles * ny <= 256) hipLaunchKernelGGL((k_rowgemm<1, 2, 1, EPI>), dim3(2 * n_tiles, ny), dim3(256), 0, st, a);
+        else if (rowgemm_lds_ok(a) && form != 1) hipLaunchKernelGGL((k_rowgemm_db<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
         else if (rowgemm_lds_ok(a)) hipLaunchKernelGGL((k_rowgemm_lds<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_rowgemm<1, 4, 1, EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
     }
