@@ -52,7 +52,7 @@ CONFIGS = {
                         "fwd+bwd+Adam"),
 }
 
-KERNEL_NAMES = {16: "k_rowgemm / k_rowgemm_lds (fp32 MFMA row GEMM)", 17: "k_rowgemm_multi", 18: "k_readout_tile_fwd",
+KERNEL_NAMES = {16: "k_rowgemm / k_rowgemm_db (fp32 MFMA row GEMM)", 17: "k_rowgemm_multi", 18: "k_readout_tile_fwd",
                 32: "k_wgrad_lds<false> (fp32 MFMA weight-gradient GEMM)", 33: "k_wgrad_lds<true>",
                 34: "k_wgrad_lds<false> one-hot (embedding gradient)", 35: "k_wgrad (direct)", 36: "k_wgrad_lds_multi<0>",
                 37: "k_wgrad_lds_multi<1> (fp32 MFMA weight-gradient GEMM of a fused step: o1 | o2 | dUcT in one launch)",
