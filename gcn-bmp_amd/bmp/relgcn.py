@@ -122,11 +122,12 @@ class RelGCN(nn.Module):
         super().__init__()
         if ch_list is None:
             ch_list = [16, 128, 64]                                            # models/relgcn.py:37
-        if input_type != 'int':
-            if input_type == 'float':
-                raise NotImplementedError("input_type='float' is not supported")
+        if input_type == 'int':
+            self.embed = EmbedID(out_size=ch_list[0], in_size=n_atom_types)
+        elif input_type == 'float':
+            self.embed = Linear(None, ch_list[0])                              # GraphLinear(None, ch_list[0]), models/relgcn.py:42-43
+        else:
             raise ValueError("[ERROR] Unexpected value input type={}".format(input_type))
-        self.embed = EmbedID(out_size=ch_list[0], in_size=n_atom_types)
         self.rgcn_convs = nn.ModuleList([RelGCNUpdate(ch_list[i], ch_list[i + 1], num_edge_type)
                                          for i in range(len(ch_list) - 1)])
         self.rgcn_readout = GGNNReadout(out_dim=out_channels, hidden_dim=ch_list[-1], nobias=True, activation="tanh")
@@ -136,7 +137,7 @@ class RelGCN(nn.Module):
 
     # ---- layout plan protocol (bmp/plan.py) ----
     def plannable(self) -> bool:
-        return True
+        return self.input_type == 'int'          # (the float form's embedding is a lazily sized GraphLinear)
 
     def primary_layouts(self):
         out = {"embed.W": self.embed.W}
@@ -215,12 +216,27 @@ class RelGCN(nn.Module):
 
     def forward(self, h, adj=None):
         """models/relgcn.py:61-73."""
-        pb = as_packed(h, adj, self.embed.W.device)
-        fast = getattr(self, "_fast", None)
-        if fast is not None:
-            return self._forward_fast(pb, fast)
-        pb.check_atom_ids(self.embed.W.shape[0])
-        x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
+        if self.input_type == 'float':
+            # float atom features (mb, A, f): every position is a row of its own (nothing can be told apart as padding);
+            # the embedding is a GraphLinear applied to every position, padded ones included (they get its bias)
+            from .ggnn import pack_float_atoms
+            dev = self.rgcn_convs[0].graph_linear_self.W.device
+            pb, rows = pack_float_atoms(h, adj, dev)
+            self.embed.materialize(rows.shape[1])
+            k = rows.shape[1]
+            kp = (k + 7) // 8 * 8
+            WT = self.embed.W.t()
+            if kp != k:
+                rows = torch.nn.functional.pad(rows, (0, kp - k))
+                WT = torch.nn.functional.pad(WT, (0, 0, 0, kp - k))
+            x = Fn.LinearRowsFn.apply(rows.contiguous(), WT.contiguous(), self.embed.b, Fn.ACT["identity"])
+        else:
+            pb = as_packed(h, adj, self.embed.W.device)
+            fast = getattr(self, "_fast", None)
+            if fast is not None:
+                return self._forward_fast(pb, fast)
+            pb.check_atom_ids(self.embed.W.shape[0])
+            x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
         pbs = rescale_adj(pb) if self.scale_adj else pb
         for conv in self.rgcn_convs:
             x = conv(x, pbs, act="tanh")                                       # :70-71

@@ -80,6 +80,46 @@ def test_float_atom_features_bypass_the_embedding():
         enc(torch.zeros(mb, A, d + 8, device=dev), j)
 
 
+def test_relgcn_float_input_type():
+    """RelGCN(input_type='float') (models/relgcn.py:42-43,61-66): the embedding is a lazily sized GraphLinear on float atom
+    features, applied to every position (padded ones get its bias)."""
+    from bmp import synth
+    from bmp.relgcn import RelGCN
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    store = synth.make_store(8, seed=5, n_lo=3, n_hi=18, n_mean=8)
+    a, j = synth.concat_mols(store)
+    mb, A = a.shape
+    f, chs = 12, [32, 64, 64]
+    dr = O._Draw(5, torch.float64, 0.1)
+    O.init_relgcn(dr, "", 16, chs)
+    p = dict(dr.p)
+    rs = np.random.RandomState(2)
+    p["embed/W"] = T(rs.normal(size=(chs[0], f)) / np.sqrt(f)); p["embed/b"] = T(rs.normal(size=chs[0]) * 0.1)
+    p = {k: v.requires_grad_() for k, v in p.items()}
+    x = T(rs.normal(size=(mb, A, f)) * (a[:, :, None] != 0)).requires_grad_()
+    # the oracle's relgcn_forward embeds ids; the float form replaces that line by the GraphLinear (models/relgcn.py:67)
+    h = O.linear(x, p["embed/W"], p["embed/b"])
+    adj = O.rescale_adj(T(j).double())
+    for i in range(2):
+        pre = f"rgcn_convs/{i}"
+        h = torch.tanh(O.relgcn_update(h, adj, p[f"{pre}/graph_linear_self/W"], p[f"{pre}/graph_linear_self/b"],
+                                       p[f"{pre}/graph_linear_edge/W"], p[f"{pre}/graph_linear_edge/b"]))
+    g_o = O.ggnn_readout_block(p, "rgcn_readout", h, None, True, "tanh", "identity")
+    wv = T(rs.normal(size=tuple(g_o.shape)))
+    (g_o * wv).sum().backward()
+    enc = RelGCN(out_channels=16, ch_list=chs, input_type='float', scale_adj=True).to(dev)
+    xd = x.detach().float().to(dev).requires_grad_()
+    g = enc(xd, j)                                   # materialises the embedding at this first call
+    load_param_dict(enc, {k: v.detach() for k, v in p.items()})
+    enc.zero_grad()
+    g = enc(xd, j)
+    (g * wv.float().to(dev)).sum().backward()
+    _close(g, g_o, "g"); _close(xd.grad, x.grad, "d features")
+    _close(enc.embed.W.grad, p["embed/W"].grad, "d embed W"); _close(enc.embed.b.grad, p["embed/b"].grad, "d embed b")
+
+
 def test_reference_construction_forms_train_on_the_gpu():
     """set_up_predictor of train_ddi_modify.py:134-150, verbatim argument forms, then one optimizer step."""
     from bmp import synth
