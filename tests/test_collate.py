@@ -107,3 +107,42 @@ def test_plan_rejects_bad_input():
         packed.collate_plan_host(nrows, ne, [np.array([2])])              # molecule index out of range
     with pytest.raises(ValueError):
         packed.collate_plan_host(nrows, ne, [np.array([0])], pad_to=[2])  # pad_to below the side's largest molecule
+
+
+def test_plan_equals_host_packer_on_random_stores():
+    """Property test (hypothesis): for arbitrary molecule sizes, batch compositions and paddings the C++ plan + the emit
+    rule reproduce the numpy packer exactly -- including one-molecule tiles, molecules that fill a tile to the last row and
+    repeated molecules."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 60), st.integers(1, 90), st.integers(0, 10 ** 6), st.booleans(), st.integers(0, 30))
+    def check(n_mols, B, seed, two_sided, extra_pad):
+        rs = np.random.RandomState(seed)
+        mols = []
+        for _ in range(n_mols):
+            n = int(rs.randint(1, 128))                      # up to 127 atoms: with the pad row exactly a full tile
+            atoms = rs.randint(1, 100, size=n).astype(np.int32)
+            nb = int(rs.randint(0, 2 * n))
+            i, j = rs.randint(0, n, nb), rs.randint(0, n, nb)
+            keep = i != j
+            key = {}
+            for a_, b_, t_ in zip(i[keep], j[keep], rs.randint(0, 4, keep.sum())):
+                key[(min(a_, b_), max(a_, b_))] = t_          # one bond per atom pair
+            bonds = np.array([(a_, b_, t_) for (a_, b_), t_ in key.items()], dtype=np.int32).reshape(-1, 3)
+            mols.append(synth.Molecule(atoms, bonds))
+        ms = packed.MolStore(mols)
+        ds = packed.DeviceMolStore(ms, "cpu")
+        sides = [rs.randint(0, n_mols, B)] + ([rs.randint(0, n_mols, B)] if two_sided else [])
+        pad_to = None
+        if extra_pad:
+            pad_to = [int(ms.n_atoms[s].max()) + extra_pad for s in sides]
+        ref = packed.pack_from_store(ms, sides, pad_to=pad_to)
+        tab, side_tiles, side_mols, n_tiles, E, n_real, max_rows = packed.collate_plan_host(ds.st_nrows, ds.st_nedges, sides, pad_to=pad_to)
+        assert (side_tiles, side_mols, n_tiles, E, n_real, max_rows) == (
+            ref.side_tiles, ref.side_mols, ref.n_tiles, ref.n_edges, ref.n_real_atoms, ref.max_rows_per_mol)
+        got = emit_numpy(ds, tab, len(tab) // 6, n_tiles, E, ref.R)
+        for k, v in got.items():
+            assert np.array_equal(v, getattr(ref, k).numpy()), k
+
+    check()
