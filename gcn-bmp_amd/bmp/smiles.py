@@ -12,8 +12,14 @@ small stand-alone reader of the SMILES grammar that keeps the atom order of the 
 * an unmarked bond between two aromatic atoms is AROMATIC if it lies in a ring and SINGLE otherwise (biphenyl);
 * explicit hydrogens ``[H]`` attached to one heavy atom are dropped, as RDKit's default sanitisation does.
 
-What it does NOT do: perceive aromaticity in Kekule input (``C1=CC=CC=C1`` stays alternating single/double, RDKit
-would mark it aromatic), valence checks, ``$`` bonds and ``*`` atoms (rejected: atom id 0 is the padding id).
+* Kekule input is aromatised the way RDKit's sanitisation would in the common cases (``C1=CC=CC=C1`` -> six AROMATIC
+  bonds): ``perceive_aromaticity`` counts pi electrons per ring of the smallest-ring set (sizes 5-7) -- 1 for an atom with
+  a double bond to another ring atom of the molecule's ring systems, 0 for a carbon whose double bond leaves the rings
+  towards O / S / N (pyridone, caffeine), 2 for N / O / S / Se / P-H without a double bond (pyrrole, furan, thiophene),
+  sp3 atoms disqualify the ring -- and marks the ring's bonds AROMATIC when the count is 4n + 2.
+
+What it does NOT do: RDKit's full aromaticity model (envelopes of fused systems such as azulene, charged rings,
+exotic elements), valence checks, ``$`` bonds and ``*`` atoms (rejected: atom id 0 is the padding id).
 PARITY UNPINNED: without RDKit nothing here can be checked against the reference's own output; tests/test_smiles.py
 holds hand-derived cases only.
 """
@@ -151,7 +157,103 @@ def parse_smiles(smiles: str) -> Tuple[np.ndarray, np.ndarray]:
             raise SmilesError("two bonds between the same pair of atoms")
         seen.add(key)
     atoms_a, bonds_a = _drop_hydrogens(np.asarray(atoms, np.int32), np.asarray(bonds, np.int32).reshape(-1, 3))
-    return atoms_a, bonds_a
+    return atoms_a, perceive_aromaticity(atoms_a, bonds_a)
+
+
+_LONE_PAIR = {7, 8, 15, 16, 34}            # N O P S Se: contribute 2 pi electrons when they carry no double bond
+_AROMATIC_Z = {5, 6, 7, 8, 15, 16, 33, 34}
+
+
+def _smallest_rings(n: int, bonds: np.ndarray, max_size: int = 7) -> List[List[int]]:
+    """For every ring bond the smallest ring through it (BFS from one end to the other without the bond); the distinct
+    rings of size <= max_size.  For the fused ring systems of drug-like molecules this is the set RDKit's SSSR gives."""
+    adj: List[List[int]] = [[] for _ in range(n)]
+    for a, b, _t in bonds:
+        adj[a].append(int(b)); adj[b].append(int(a))
+    rings, seen = [], set()
+    for a, b, _t in bonds:
+        a, b = int(a), int(b)
+        prev = {a: -1}
+        frontier = [a]
+        found = False
+        while frontier and not found:
+            nxt = []
+            for v in frontier:
+                for w in adj[v]:
+                    if (v == a and w == b) or w in prev:
+                        continue
+                    prev[w] = v
+                    if w == b:
+                        found = True
+                        break
+                    nxt.append(w)
+                if found:
+                    break
+            frontier = nxt
+        if not found:
+            continue
+        path = [b]
+        while path[-1] != a:
+            path.append(prev[path[-1]])
+        if len(path) > max_size:
+            continue
+        key = frozenset(path)
+        if key not in seen:
+            seen.add(key)
+            rings.append(path)
+    return rings
+
+
+def perceive_aromaticity(atoms: np.ndarray, bonds: np.ndarray) -> np.ndarray:
+    """Kekule -> aromatic bond types by pi-electron counting per ring (see the module docstring).  Bonds that are already
+    AROMATIC (aromatic SMILES) stay; rings mixing aromatic and Kekule notation are left alone."""
+    if len(bonds) == 0:
+        return bonds
+    n = len(atoms)
+    bonds = bonds.copy()
+    rings = [r for r in _smallest_rings(n, bonds) if 5 <= len(r) <= 7]
+    if not rings:
+        return bonds
+    in_ring = np.zeros(n, dtype=bool)
+    for r in rings:
+        in_ring[r] = True
+    btype: Dict[Tuple[int, int], int] = {}
+    nbrs: List[List[Tuple[int, int]]] = [[] for _ in range(n)]
+    for k, (a, b, t) in enumerate(bonds.tolist()):
+        btype[(min(a, b), max(a, b))] = k
+        nbrs[a].append((b, t)); nbrs[b].append((a, t))
+
+    def electrons(v: int) -> int:
+        """pi electrons atom v brings to a ring it is part of; -1: the atom cannot be aromatic."""
+        z = int(atoms[v])
+        if z not in _AROMATIC_Z:
+            return -1
+        doubles = [(w, t) for w, t in nbrs[v] if t == DOUBLE]
+        if any(t == TRIPLE for _w, t in nbrs[v]) or len(doubles) > 1:
+            return -1
+        if doubles:
+            w = doubles[0][0]
+            if in_ring[w]:
+                return 1                                   # a ring double bond (this ring's or a fused neighbour's)
+            if z == 6 and int(atoms[w]) in (7, 8, 16):
+                return 0                                   # exocyclic C=O / C=S / C=N: sp2 carbon with an empty p orbital
+            return -1
+        if any(t == AROMATIC for _w, t in nbrs[v]):
+            return -1                                      # already aromatic notation: leave such rings alone
+        if z in _LONE_PAIR and len(nbrs[v]) <= 3:
+            return 2
+        return -1                                          # sp3 carbon (cyclopentadiene's CH2, cyclohexene's CH2)
+
+    for r in rings:
+        es = [electrons(v) for v in r]
+        if min(es) < 0 or (sum(es) - 2) % 4 != 0:
+            continue
+        ring_pairs = [(r[k], r[(k + 1) % len(r)]) for k in range(len(r))]
+        if any(bonds[btype[(min(a, b), max(a, b))], 2] == TRIPLE for a, b in ring_pairs):
+            continue
+        for a, b in ring_pairs:
+            bonds[btype[(min(a, b), max(a, b))], 2] = AROMATIC
+    return bonds
 
 
 def _bridges(n: int, bonds: Sequence[Sequence[int]]) -> List[bool]:
