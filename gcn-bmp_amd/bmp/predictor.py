@@ -66,6 +66,13 @@ class GraphConvPredictorForPair(nn.Module):
             t2 = torch.sigmoid(self.forward(atoms_2, adjs_2, atoms_1, adjs_1))
             return torch.maximum(t1, t2) if self.symmetric == 'or' else torch.minimum(t1, t2)
 
+    def predict_eval(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
+        """The ``predict`` of eval_coattention.py:103-124 (the evaluation script re-declares the class with this form):
+        logits -- no sigmoid -- and the two molecule vectors handed to the link predictor, under no-backprop."""
+        with torch.no_grad():
+            h = self.forward(atoms_1, adjs_1, atoms_2, adjs_2)
+            return h, (self.g1, self.g2)
+
     @staticmethod
     def loss(y, t):
         return sigmoid_cross_entropy(y, t)

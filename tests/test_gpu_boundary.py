@@ -151,6 +151,8 @@ def test_reference_construction_forms_train_on_the_gpu():
     assert losses[-1] < losses[0], losses
     prob = predictor.predict(a1, j1, a2, j2)
     assert prob.shape == (6, 1) and ((prob > 0) & (prob < 1)).all()
+    h, (g1, g2) = predictor.predict_eval(a1, j1, a2, j2)                # eval_coattention.py:103-124: logits + the two vectors
+    assert torch.allclose(torch.sigmoid(h), prob) and g1.shape == (6, 16) and g2.shape == (6, 16) and not h.requires_grad
 
 
 def test_dropout_is_identity_in_eval_mode():
