@@ -23,15 +23,17 @@ SIGNATURES = {
     "bmp_prof_start": (_I, [_I]),
     "bmp_prof_stop": (_I, [_P]),
     "bmp_prof_collect": (_I, [_P, _P, _P, _P, _P, _I]),
+    "bmp_stream_create_low": (_I, [_P]),
+    "bmp_stream_destroy": (_I, [_P]),
     "bmp_embed_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "bmp_embed_bwd_ws_floats": (_Z, [_I, _I, _I]),
     "bmp_embed_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, _P]),
     "bmp_msg_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "bmp_msg_bwd_ws_floats": (_Z, [_I, _I, _I]),
-    "bmp_msg_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_msg_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P, _P]),
     "bmp_gru_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bmp_gru_bwd_ws_floats": (_Z, [_I, _I]),
-    "bmp_gru_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_gru_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P, _P]),
     "bmp_gru_state_fwd": (_I, [_P, _P, _P, _I, _I] + [_P] * 8),
     "bmp_gru_state_bwd_ws_floats": (_Z, [_I, _I]),
     "bmp_gru_state_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11 + [_Z, _P]),
@@ -49,7 +51,7 @@ SIGNATURES = {
     "bmp_relgcn_layer_wgrad": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "bmp_readout_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "bmp_readout_bwd_ws_floats": (_Z, [_I, _I, _I, _I]),
-    "bmp_readout_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_readout_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _Z, _P, _P]),
     "bmp_linear_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P]),
     "bmp_wgrad_ws_floats_c": (_Z, [_I, _I, _I]),
     "bmp_linear_wgrad": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _P]),

@@ -107,7 +107,7 @@ class MsgFn(Function):
         ws = _ws(nws, dev)
         check(L.bmp_msg_bwd(ptr(dout), d_out, ptr(out), d_out, ctx.act, ptr(x), d_in, pb.n_tiles, d_in, d_out,
                             ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(Ws), ptr(agg), ptr(wdeg),
-                            ptr(dx), ptr(dWT), ptr(dbE), ptr(dWsT), ptr(dbs), ptr(ws), nws, stream()), "bmp_msg_bwd")
+                            ptr(dx), ptr(dWT), ptr(dbE), ptr(dWsT), ptr(dbs), 0, ptr(ws), nws, stream(), None), "bmp_msg_bwd")
         return dx, dWT, dbE, dWsT, (dbs if ctx.has_bs else None), None, None
 
 
@@ -150,7 +150,7 @@ class GRUFn(Function):
         nws = L.bmp_gru_bwd_ws_floats(pb.n_tiles, d)
         ws = _ws(nws, dev)
         check(L.bmp_gru_bwd(ptr(dhout), ptr(h), ptr(m), ptr(rz), ptr(c), pb.n_tiles, d, ctx.first, ptr(A), ptr(Uc),
-                            ptr(dh), ptr(dm), ptr(dAT), ptr(dUcT), ptr(db), ptr(ws), nws, stream()), "bmp_gru_bwd")
+                            ptr(dh), ptr(dm), ptr(dAT), ptr(dUcT), ptr(db), 0, ptr(ws), nws, stream(), None), "bmp_gru_bwd")
         return dh, dm, dAT, dUcT, db, None, None
 
 
@@ -353,7 +353,7 @@ class ReadoutFn(Function):
         ws = _ws(nws, dev)
         check(L.bmp_readout_bwd(ptr(dg), ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(Wnat), ptr(ij), ctx.act_j,
                                 ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0), ptr(dWT),
-                                ptr(db), ptr(ws), nws, stream()), "bmp_readout_bwd")
+                                ptr(db), 0, ptr(ws), nws, stream(), None), "bmp_readout_bwd")
         return dh, dh0, dWT, db, None, None
 
 
@@ -434,6 +434,34 @@ def _first_write(state, key) -> bool:
     return nb % nf == 0
 
 
+def _on_side(state, keep, launch) -> None:
+    """Weight-gradient launches of the planned path: nothing in the backward chain reads their outputs (the plan's gradient
+    buffers, folded into the flat gradient by LayoutPlan.collect), so they may run beside the chain.  With a side stream in
+    the plan's state (plan.SideStream: lowest priority, its own workspace) they are enqueued there, behind everything the
+    current stream has been given so far: the chain's tile kernels leave the CUs of their last, partly filled round idle
+    (455 tiles on 256 CUs) and these workgroups take them, giving way to the chain otherwise.  ``launch(st, ws)`` gets the
+    stream handle and a workspace allocator; ``keep``: the row tensors it reads, held until the streams have joined."""
+    side = state.get("side") if state is not None else None
+    if side is None:
+        launch(stream(), _ws)
+        return
+    side.stream.wait_stream(torch.cuda.current_stream())
+    launch(side.handle, side.workspace)
+    side.keep.append(keep)
+    state["side_used"] = True
+
+
+def _side_handle(state, keep):
+    """The ``stream_w`` argument of bmp_msg_bwd / bmp_gru_bwd / bmp_readout_bwd: the plan's side stream (the entry point
+    itself orders it behind the operands it produces), with ``keep`` held until the streams have joined; None = in line."""
+    side = state.get("side") if state is not None else None
+    if side is None:
+        return None
+    side.keep.append(keep)
+    state["side_used"] = True
+    return side.handle
+
+
 class PEmbedFn(Function):
     @staticmethod
     def forward(ctx, tape, W, ids, dW, state):
@@ -494,10 +522,14 @@ class PStepFn(Function):
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
                                   ptr(dh), ptr(gda), stream()), "bmp_ggnn_step_bwd")
         acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
-        nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
-        ws = _ws(nws, h.device)
-        check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(G["o1"]), ptr(G["o2"]),
-                                    ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+
+        def wgrad(st, ws_of):
+            nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
+            ws = ws_of(nws, h.device)
+            check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(G["o1"]), ptr(G["o2"]),
+                                        ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
+
+        _on_side(ctx.state, (h, m, rz, gda), wgrad)
         return dh, None, None, None, None, None, None
 
 
@@ -534,16 +566,11 @@ class PReadoutFn(Function):
         dh0 = None if h0 is None else torch.empty_like(h0)
         nws = L.bmp_readout_bwd_ws_floats(pb.n_tiles, d, d0, o)
         ws = _ws(nws, h.device)
-        first = _first_write(ctx.state, "ro")
-        dWT = G["dWT"] if first else torch.empty_like(G["dWT"])
-        db = None if G.get("db") is None else (G["db"] if first else torch.empty_like(G["db"]))
+        acc = 0 if _first_write(ctx.state, "ro") else 1
         check(L.bmp_readout_bwd(ptr(dg), ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(W["Wnat"]), ptr(ij), ctx.act_j,
                                 ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0),
-                                ptr(dWT), ptr(db), ptr(ws), nws, stream()), "bmp_readout_bwd")
-        if not first:
-            G["dWT"].add_(dWT)
-            if db is not None:
-                G["db"].add_(db)
+                                ptr(G["dWT"]), ptr(G.get("db")), acc, ptr(ws), nws, stream(),
+                                _side_handle(ctx.state, (h, h0, ws))), "bmp_readout_bwd")
         return dh, dh0, None, None, None, None, None
 
 
@@ -575,15 +602,12 @@ class PGRUFn(Function):
         N, d = h.shape
         dhout = dhout.contiguous()
         dh, dm = torch.empty_like(h), torch.empty_like(m)
-        first_w = _first_write(ctx.state, ctx.gkey)
-        T = G if first_w else {k: torch.empty_like(v) for k, v in G.items()}
+        acc = 0 if _first_write(ctx.state, ctx.gkey) else 1          # a tied step's later calls add into the slots
         nws = L.bmp_gru_bwd_ws_floats(pb.n_tiles, d)
         ws = _ws(nws, h.device)
         check(L.bmp_gru_bwd(ptr(dhout), ptr(h), ptr(m), ptr(rz), ptr(c), pb.n_tiles, d, ctx.first, ptr(W["A"]), ptr(W["Uc"]),
-                            ptr(dh), ptr(dm), ptr(T["dAT"]), ptr(T["dUcT"]), ptr(T["db"]), ptr(ws), nws, stream()), "bmp_gru_bwd")
-        if not first_w:
-            for k in G:
-                G[k].add_(T[k])
+                            ptr(dh), ptr(dm), ptr(G["dAT"]), ptr(G["dUcT"]), ptr(G["db"]), acc, ptr(ws), nws, stream(),
+                            _side_handle(ctx.state, (h, m, rz, ws))), "bmp_gru_bwd")
         return dh, dm, None, None, None, None, None, None
 
 
@@ -616,17 +640,13 @@ class PMsgFn(Function):
         N, d_out = dout.shape
         d_in = x.shape[1]
         dx = torch.empty(N, d_in, dtype=torch.float32, device=x.device)
-        first = _first_write(ctx.state, ctx.gkey)
-        T = G if first else {k: torch.empty_like(v) for k, v in G.items()}
+        acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
         nws = L.bmp_msg_bwd_ws_floats(pb.n_tiles, d_in, d_out)
         ws = _ws(nws, x.device)
         check(L.bmp_msg_bwd(ptr(dout), d_out, ptr(out), d_out, ctx.act, ptr(x), d_in, pb.n_tiles, d_in, d_out,
                             ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat"]), ptr(W.get("Ws")), ptr(agg),
-                            ptr(wdeg), ptr(dx), ptr(T["dWT"]), ptr(T["dbE"]), ptr(T.get("dWsT")), ptr(T.get("dbs")), ptr(ws), nws,
-                            stream()), "bmp_msg_bwd")
-        if not first:
-            for k in G:
-                G[k].add_(T[k])
+                            ptr(wdeg), ptr(dx), ptr(G["dWT"]), ptr(G["dbE"]), ptr(G.get("dWsT")), ptr(G.get("dbs")), acc, ptr(ws),
+                            nws, stream(), _side_handle(ctx.state, (x, agg, wdeg, dout, ws))), "bmp_msg_bwd")
         return dx, None, None, None, None, None, None
 
 
@@ -644,17 +664,21 @@ def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act):
     return out, wdeg
 
 
-def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate):
+def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate, state=None):
     L = _lib.lib()
     N, d = x.shape
     dx = torch.empty(N, d, dtype=torch.float32, device=x.device)
     gda = torch.empty(N, 5 * d, dtype=torch.float32, device=x.device)
     check(L.bmp_relgcn_layer_bwd(ptr(dout), ptr(out), act, pb.n_tiles, d, ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val),
                                  ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), stream()), "bmp_relgcn_layer_bwd")
-    nws = L.bmp_relgcn_layer_wgrad_ws_floats(N, d)
-    ws = _ws(nws, x.device)
-    check(L.bmp_relgcn_layer_wgrad(ptr(x), ptr(wdeg), ptr(gda), N, d, ptr(o1), ptr(dbE), ptr(cs), int(accumulate), ptr(ws), nws,
-                                   stream()), "bmp_relgcn_layer_wgrad")
+
+    def wgrad(st, ws_of):
+        nws = L.bmp_relgcn_layer_wgrad_ws_floats(N, d)
+        ws = ws_of(nws, x.device)
+        check(L.bmp_relgcn_layer_wgrad(ptr(x), ptr(wdeg), ptr(gda), N, d, ptr(o1), ptr(dbE), ptr(cs), int(accumulate), ptr(ws),
+                                       nws, st), "bmp_relgcn_layer_wgrad")
+
+    _on_side(state, (x, wdeg, gda), wgrad)
     return dx
 
 
@@ -704,5 +728,5 @@ class PRelLayerFn(Function):
         W, G = ctx.W, ctx.G
         first = _first_write(ctx.state, ctx.gkey)
         dx = _rel_bwd(dout.contiguous(), out, x, wdeg, ctx.pb, W["Wnat_p"], W["Ws_p"], ctx.act, G["o1"], G["dbE"], G["cs"],
-                      0 if first else 1)
+                      0 if first else 1, ctx.state)
         return dx, None, None, None, None, None, None

@@ -16,6 +16,7 @@ the oracle), the two paths cannot drift apart; tests/test_plan.py checks them ag
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -72,6 +73,43 @@ def _index_eval(mod: nn.Module, fn_name: str, params: List[torch.Tensor]) -> Dic
     return out
 
 
+class SideStream:
+    """A lowest-priority HIP stream (bmp_stream_create_low) with a workspace of its own, for the launches
+    functional._on_side puts beside the backward chain."""
+
+    def __init__(self, device):
+        import ctypes
+        device = torch.device(device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(_lib.lib().bmp_stream_create_low(ctypes.byref(h)), "bmp_stream_create_low")
+        self.handle = h
+        self.stream = torch.cuda.ExternalStream(h.value, device=device)
+        self.ws = None
+        self.keep: list = []          # what the enqueued launches read: released once the streams have joined
+
+    def workspace(self, nfloats: int, device) -> torch.Tensor:
+        if self.ws is None or self.ws.numel() < nfloats:
+            if self.ws is not None:
+                self.keep.append(self.ws)
+            self.ws = torch.empty(max(int(nfloats), 4), dtype=torch.float32, device=device)
+            self.stream.wait_stream(torch.cuda.current_stream())       # the block's earlier users are on that stream
+        return self.ws
+
+    def join(self) -> None:
+        """The current stream waits for everything enqueued here; the held tensors go back to the allocator (whatever
+        reuses them is enqueued behind the wait)."""
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+    def __del__(self):
+        try:
+            self.stream.synchronize()
+            _lib.lib().bmp_stream_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class LayoutPlan:
     """Built for a list of (prefix, module) pairs whose parameters are slices of one flat fp32 buffer.
     A module takes part if it defines ``prepared_layouts()``, ``primary_layouts()``, ``gk_spec()`` and
@@ -112,6 +150,10 @@ class LayoutPlan:
         self.tab_g = torch.from_numpy(tab_g).to(device)
         self.prep = torch.empty(max(prep_off, 1), dtype=torch.float32, device=device)
         self.gk = torch.zeros(max(gk_off, 1), dtype=torch.float32, device=device)
+        # weight-gradient launches beside the backward chain (functional._on_side): BMP_WGRAD_STREAM=0 keeps them in line
+        # weight-gradient launches beside the backward chain (functional._on_side); BMP_WGRAD_STREAM=0 keeps them in line
+        self.side = SideStream(device) if (torch.device(device).type == "cuda"
+                                           and os.environ.get("BMP_WGRAD_STREAM", "1") != "0") else None
         self.state: Dict[str, dict] = {}
         self._views()
 
@@ -174,12 +216,17 @@ class LayoutPlan:
                   "bmp_gather_sum(prepare)")
         else:       # host form of the same table walk (tests of the tables without a GPU)
             self.prep.copy_(gather_sum_host(flat.detach(), self.tab_p_host))
-        self.state = {}
+        if self.state.get("side_used"):              # a backward whose gradients nobody collected
+            self.side.join()
+        self.state = {"side": self.side} if self.side is not None else {}
         self.gk.zero_()          # a buffer no backward kernel writes this step (an unused readout, ...) must read as zero
 
     def collect(self, flat_grad: torch.Tensor) -> None:
         """One launch: flat_grad[j] += the parameter gradients folded out of the kernels' buffers."""
         if flat_grad.is_cuda:
+            if self.state.get("side_used"):          # the side stream's weight gradients land in gk
+                self.side.join()
+                self.state["side_used"] = False
             check(_lib.lib().bmp_gather_sum(ptr(flat_grad), self.n_flat, ptr(self.gk), ptr(self.tab_g), self.Kg, 1,
                                             stream()), "bmp_gather_sum(collect)")
         else:

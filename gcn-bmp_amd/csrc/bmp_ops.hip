@@ -120,12 +120,26 @@ extern "C" size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out) {
 }
 
 // Wnat [d_out x 4*d_in] = WT^T ; Ws [d_out x d_in] = WsT^T (reference Linear layout).
+// The weight-gradient launches of a backward entry point may go to a stream of their own (st_w; null or == st: in line):
+// nothing downstream in the chain reads them.  st_w picks up after everything st has been given so far.
+static int fork_to(hipStream_t st, hipStream_t st_w) {
+    if (!st_w || st_w == st) return 0;
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventRecord(ev, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st_w, ev, 0);
+    (void)hipEventDestroy(ev);                      // released once the record has completed
+    return (int)e;
+}
+
 extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ldo, int act, const float* x, int ldx,
                            int n_tiles, int d_in, int d_out, const int* csrT_ptr, const int* csrT_col,
                            const float* csrT_val, const float* Wnat, const float* Ws, const float* agg, const float* wdeg,
-                           float* dx, float* dWT, float* dbE, float* dWsT, float* dbs, float* ws, size_t ws_floats,
-                           hipStream_t st) {
+                           float* dx, float* dWT, float* dbE, float* dWsT, float* dbs, int accumulate_w, float* ws,
+                           size_t ws_floats, hipStream_t st, hipStream_t st_w) {
     BMP_REQUIRE(n_tiles > 0 && (d_in & 7) == 0 && (d_out & 7) == 0 && d_in > 0 && d_out > 0);
+    const int acc = accumulate_w ? 1 : 0;          // the weight gradients add into their outputs (a tied layer's later calls)
     BMP_REQUIRE(ws_floats >= bmp_msg_bwd_ws_floats(n_tiles, d_in, d_out));
     const int N = n_tiles * BMP_R;
     float* dagg = ws;
@@ -143,6 +157,8 @@ extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ld
         BMP_REQUIRE((lddo & 3) == 0);
     }
     int rc;
+    if (!st_w) st_w = st;
+    if ((rc = fork_to(st, st_w))) return rc;        // dpre is complete: the weight gradients may start
     // dagg = dpre . Wnat
     {
         RGArgs a = rg_zero();
@@ -162,16 +178,16 @@ extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ld
     if ((rc = bmp_launch_gather_bwd(dagg, N, d_in, csrT_ptr, csrT_col, csrT_val, dx, d_in, accumulate, st))) return rc;
     // weight gradients
     {
-        WGArgs g{agg, nullptr, 4 * d_in, 0, dpre, lddp, 4 * d_in, d_out, N, dWT, d_out, 0};
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
+        WGArgs g{agg, nullptr, 4 * d_in, 0, dpre, lddp, 4 * d_in, d_out, N, dWT, d_out, acc};
+        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
     }
     {
-        WGArgs g{wdeg, nullptr, 4, 0, dpre, lddp, 4, d_out, N, dbE, d_out, 0};
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
+        WGArgs g{wdeg, nullptr, 4, 0, dpre, lddp, 4, d_out, N, dbE, d_out, acc};
+        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
     }
     if (Ws) {
-        WGArgs g{x, nullptr, ldx, 0, dpre, lddp, d_in, d_out, N, dWsT, d_out, 0, dbs};      // + dbs = column sums of dpre
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
+        WGArgs g{x, nullptr, ldx, 0, dpre, lddp, d_in, d_out, N, dWsT, d_out, acc, dbs};      // + dbs = column sums of dpre
+        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
     }
     return 0;
 }
@@ -232,9 +248,11 @@ extern "C" size_t bmp_gru_bwd_ws_floats(int n_tiles, int d) {
 // A [3d x 2d] = AT^T (rows r|z|c, cols h-part|m-part) ; Uc [d x d] = U (reference layout, out x in).
 extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float* rz, const float* c,
                            int n_tiles, int d, int first, const float* A, const float* Uc, float* dh, float* dm,
-                           float* dAT, float* dUcT, float* db, float* ws, size_t ws_floats, hipStream_t st) {
+                           float* dAT, float* dUcT, float* db, int accumulate_w, float* ws, size_t ws_floats,
+                           hipStream_t st, hipStream_t st_w) {
     BMP_REQUIRE(n_tiles > 0 && d > 0 && (d & 7) == 0);
     BMP_REQUIRE(ws_floats >= bmp_gru_bwd_ws_floats(n_tiles, d));
+    const int acc = accumulate_w ? 1 : 0;          // the weight gradients add into their outputs (a tied step's later calls)
     const int N = n_tiles * BMP_R;
     float* da = ws;                              // [N x 3d]  (da_r | da_z | da_c), pre-activation grads
     float* dhacc = da + (size_t)N * 3 * d;       // [N x d]
@@ -253,6 +271,8 @@ extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, c
         a.o1 = dhacc; a.ldo1 = d;
         if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GRU_DRH, st))) return rc;
     }
+    if (!st_w) st_w = st;
+    if ((rc = fork_to(st, st_w))) return rc;        // da is complete: the weight gradients may start
     {   // [dh | dm] = da . A ; dh += dhacc
         RGArgs a = rg_zero();
         a.s[0] = RGSrc{da, nullptr, A, 3 * d, 0, 2 * d, 3 * d};
@@ -265,16 +285,16 @@ extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, c
     }
     {   // dAT rows 0..d-1 = h^T . da ; rows d..2d-1 = m^T . da
         // db = column sums of da: carried by the first GEMM (it reads da anyway; a pass of its own re-read N x 3d floats)
-        WGArgs g{h, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT, 3 * d, 0, db};
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
-        WGArgs g2{m, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT + (size_t)d * 3 * d, 3 * d, 0};
-        if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
+        WGArgs g{h, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT, 3 * d, acc, db};
+        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
+        WGArgs g2{m, nullptr, d, 0, da, 3 * d, d, 3 * d, N, dAT + (size_t)d * 3 * d, 3 * d, acc};
+        if ((rc = bmp_launch_wgrad(g2, slab, st_w))) return rc;
     }
     if (!first) {   // dUcT = (r*h)^T . da_c
-        WGArgs g{rz, h, 2 * d, d, da + 2 * d, 3 * d, d, d, N, dUcT, d, 0};
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
-    } else {
-        hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st);
+        WGArgs g{rz, h, 2 * d, d, da + 2 * d, 3 * d, d, d, N, dUcT, d, acc};
+        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
+    } else if (!acc) {
+        hipError_t e = hipMemsetAsync(dUcT, 0, (size_t)d * d * sizeof(float), st_w);
         if (e != hipSuccess) return (int)e;
     }
     return 0;
@@ -420,8 +440,8 @@ extern "C" size_t bmp_readout_bwd_ws_floats(int n_tiles, int d, int d0, int o) {
 // Wnat [2o x (d + d0)] = WT^T.
 extern "C" int bmp_readout_bwd(const float* dg, const float* h, const float* h0, int n_tiles, int d, int d0, int o,
                                const float* Wnat, const float* ij, int act_j, const float* row_w, const int* mol_row0,
-                               const int* mol_nrows, int n_mols, float* dh, float* dh0, float* dWT, float* db, float* ws,
-                               size_t ws_floats, hipStream_t st) {
+                               const int* mol_nrows, int n_mols, float* dh, float* dh0, float* dWT, float* db,
+                               int accumulate_w, float* ws, size_t ws_floats, hipStream_t st, hipStream_t st_w) {
     BMP_REQUIRE(n_tiles > 0 && d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && n_mols > 0);
     if (!h0) d0 = 0;
     BMP_REQUIRE(ws_floats >= bmp_readout_bwd_ws_floats(n_tiles, d, d0, o));
@@ -433,6 +453,9 @@ extern "C" int bmp_readout_bwd(const float* dg, const float* h, const float* h0,
     hipLaunchKernelGGL(k_readout_bwd_rows, dim3(n_mols), dim3(256), 0, st, dg, ij, o, act_j, row_w, mol_row0, mol_nrows, dij);
     BMP_LAUNCH_CHECK();
     int rc;
+    const int acc = accumulate_w ? 1 : 0;
+    if (!st_w) st_w = st;
+    if ((rc = fork_to(st, st_w))) return rc;        // dij is complete
     {   // [dh | dh0] = dij . Wnat
         RGArgs a = rg_zero();
         a.s[0] = RGSrc{dij, nullptr, Wnat, 2 * o, 0, d + d0, 2 * o};
@@ -442,11 +465,11 @@ extern "C" int bmp_readout_bwd(const float* dg, const float* h, const float* h0,
         if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st))) return rc;
     }
     {
-        WGArgs g{h, nullptr, d, 0, dij, 2 * o, d, 2 * o, N, dWT, 2 * o, 0, db};            // + db = column sums of dij (db may be null)
-        if ((rc = bmp_launch_wgrad(g, slab, st))) return rc;
+        WGArgs g{h, nullptr, d, 0, dij, 2 * o, d, 2 * o, N, dWT, 2 * o, acc, db};          // + db = column sums of dij (db may be null)
+        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
         if (h0) {
-            WGArgs g2{h0, nullptr, d0, 0, dij, 2 * o, d0, 2 * o, N, dWT + (size_t)d * 2 * o, 2 * o, 0};
-            if ((rc = bmp_launch_wgrad(g2, slab, st))) return rc;
+            WGArgs g2{h0, nullptr, d0, 0, dij, 2 * o, d0, 2 * o, N, dWT + (size_t)d * 2 * o, 2 * o, acc};
+            if ((rc = bmp_launch_wgrad(g2, slab, st_w))) return rc;
         }
     }
     return 0;

@@ -65,3 +65,15 @@ extern "C" int bmp_prof_collect(int* key, int* count, double* ms, double* flops,
     g_cls = 0;
     return n;
 }
+
+// A stream of the lowest priority the device offers, for launches that run BESIDE a dependent chain (the weight-gradient
+// GEMMs of the backward: bmp/functional.py _on_side): their workgroups take the CUs the chain's tile kernels leave idle in
+// their last round and give way to the chain otherwise.  The caller destroys it with bmp_stream_destroy.
+extern "C" int bmp_stream_create_low(hipStream_t* out) {
+    if (!out) return (int)hipErrorInvalidValue;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamCreateWithPriority(out, hipStreamNonBlocking, least);
+}
+extern "C" int bmp_stream_destroy(hipStream_t st) { return st ? (int)hipStreamDestroy(st) : 0; }

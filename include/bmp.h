@@ -44,6 +44,17 @@ int bmp_prof_stop(double* out);
  * number of distinct keys. */
 int bmp_prof_collect(int* key, int* count, double* ms, double* flops, double* bytes, int cap);
 
+/* A stream of the device's lowest priority for launches that run beside a dependent chain (no reference counterpart:
+ * chainer runs one stream).  The backward's weight-gradient GEMMs go there: nothing in the chain reads their output, and
+ * their workgroups fill the CUs the tile kernels' last round leaves idle.  Destroy with bmp_stream_destroy. */
+/* bmp_msg_bwd, bmp_gru_bwd and bmp_readout_bwd take that stream as `stream_w` (NULL or == stream: everything in line):
+ * their weight-gradient launches go there, ordered behind what `stream` has been given up to the point inside the call
+ * where their operands are complete.  The workspace `ws` is then read on both streams: the caller keeps it (and the row
+ * tensors) alive until the two streams have joined.  accumulate_w != 0: the weight gradients add into their outputs (the
+ * later calls of a tied layer). */
+int bmp_stream_create_low(bmp_stream_t* out);
+int bmp_stream_destroy(bmp_stream_t stream);
+
 /* EmbedAtomID lookup -- chainer_chemistry EmbedAtomID used at models/ggnn.py:85,603
  * (models/relgcn.py:40,67): out[row,:] = W[ids[row],:], W [V x d].  Ids outside [0, V) are the caller's error (the Python
  * wrappers raise ValueError before any launch, as chainer's EmbedID type check does); the kernels never leave the table:
@@ -66,7 +77,7 @@ size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out);
 int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ldo, int act, const float* x, int ldx, int n_tiles,
                 int d_in, int d_out, const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat,
                 const float* Ws, const float* agg, const float* wdeg, float* dx, float* dWT, float* dbE, float* dWsT,
-                float* dbs, float* ws, size_t ws_floats, bmp_stream_t stream);
+                float* dbs, int accumulate_w, float* ws, size_t ws_floats, bmp_stream_t stream, bmp_stream_t stream_w);
 
 /* GRU node update -- chainer links.GRU (StatefulGRU) at models/ggnn.py:132,254-262
  * (models/update/ggnn_update.py:28,61).  first != 0 selects the first-call-after-reset branch.
@@ -77,7 +88,7 @@ int bmp_gru_fwd(const float* h, const float* m, int n_tiles, int d, int first, c
 size_t bmp_gru_bwd_ws_floats(int n_tiles, int d);
 int bmp_gru_bwd(const float* dhout, const float* h, const float* m, const float* rz, const float* c, int n_tiles, int d,
                 int first, const float* A, const float* Uc, float* dh, float* dm, float* dAT, float* dUcT, float* db,
-                float* ws, size_t ws_floats, bmp_stream_t stream);
+                int accumulate_w, float* ws, size_t ws_floats, bmp_stream_t stream, bmp_stream_t stream_w);
 
 /* The same update with the GRU state apart from its input: dropout on the step output (models/ggnn.py:626-627) feeds the
  * next step x = [hd, m] with hd = dropout(s) while the stateful GRU keeps the un-dropped s.  Later calls only (the first
@@ -142,8 +153,8 @@ int bmp_readout_fwd(const float* h, const float* h0, int n_tiles, int d, int d0,
 size_t bmp_readout_bwd_ws_floats(int n_tiles, int d, int d0, int o);
 int bmp_readout_bwd(const float* dg, const float* h, const float* h0, int n_tiles, int d, int d0, int o,
                     const float* Wnat, const float* ij, int act_j, const float* row_w, const int* mol_row0,
-                    const int* mol_nrows, int n_mols, float* dh, float* dh0, float* dWT, float* db, float* ws,
-                    size_t ws_floats, bmp_stream_t stream);
+                    const int* mol_nrows, int n_mols, float* dh, float* dh0, float* dWT, float* db, int accumulate_w,
+                    float* ws, size_t ws_floats, bmp_stream_t stream, bmp_stream_t stream_w);
 /* The same forward as one kernel per tile when bmp_readout_tile_supported(d, d0, o) (d == o in {64, 128}, d0 in {0, d}):
  * WT K4-packed as for bmp_ggnn_step_*, row_mol [N] = molecule of every packed row (-1: none).  Every molecule lies in
  * one tile, whose workgroup takes its sum in a fixed order. */
