@@ -88,7 +88,7 @@ SIGNATURES = {
     "bmp_coattn_zcols": (_I, [_I, _I]),
     "bmp_coattn_nie_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 17 + [_P]),
     "bmp_coattn_nie_bwd_ws_floats": (_Z, [_I] * 6),
-    "bmp_coattn_nie_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 21 + [_Z, _P]),
+    "bmp_coattn_nie_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 21 + [_Z, _P, _P]),
 }
 
 _lib = None

@@ -17,7 +17,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, stream
-from .functional import ACT, _ws
+from .functional import ACT, _side_handle, _ws
 from .ggnn import Linear, PackedAtoms, as_packed_atoms
 
 
@@ -148,7 +148,7 @@ class NieCoattnFn(Function):
                                    ptr(wa2),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
-                                   stream()), "bmp_coattn_nie_bwd")
+                                   stream(), None), "bmp_coattn_nie_bwd")
         return (dX1, dX2, dWbT, dZW1T, dZW2T, dzb, dwa[:H], dwa[H:2 * H], dwa[2 * H:], None, None, None, None, None,
                 None, None, None)
 
@@ -158,9 +158,10 @@ class PNieFn(Function):
     G: dWbT, dZW1T, dZW2T, dzb, dwa."""
 
     @staticmethod
-    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode):
+    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode, state=None):
         L = _lib.lib()
         dev = X1.device
+        ctx.state = state
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         ZC = L.bmp_coattn_zcols(o, H)
         ctx.joint = X2 is None          # one row tensor for both sides: its gradient comes back as ONE tensor too
@@ -205,14 +206,17 @@ class PNieFn(Function):
                                    ptr(W["ZW2"]), ptr(W["wa1"]), ptr(W["wa2"]),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(G["dWbT"]), ptr(G["dZW1T"]), ptr(G["dZW2T"]), ptr(G["dzb"]), ptr(G["dwa"]),
-                                   ptr(ws), nws, stream()), "bmp_coattn_nie_bwd")
+                                   ptr(ws), nws, stream(), _side_handle(ctx.state, (X1, X2, ws))), "bmp_coattn_nie_bwd")
         if ctx.joint:
-            return dX, None, None, None, None, None, None, None, None, None, None, None
-        return dX1, dX2, None, None, None, None, None, None, None, None, None, None
+            return dX, None, None, None, None, None, None, None, None, None, None, None, None
+        return dX1, dX2, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _FinePlanMixin:
     """Layout plan protocol (bmp/plan.py) of the fine co-attention family, on top of ``_kernel_weights()``."""
+
+    # the family's __call__ never reads g_1 / g_2 (nie_coattention.py:335-370): the pair predictor may tell the encoder so
+    ignores_graph_vectors = True
 
     def plannable(self) -> bool:
         return True
@@ -237,12 +241,12 @@ class _FinePlanMixin:
                 "wa1": [gk["dwa"][:H]], "wa2": [gk["dwa"][H:2 * H]], "cbias": [gk["dwa"][2 * H:]]}
 
     def _forward_fast(self, atoms_1, atoms_2, fast, mode):
-        P, G, _state, _tape = fast
+        P, G, state, _tape = fast
         X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
         if joint:
             X1, X2 = atoms_1.rows, None
         return PNieFn.apply(X1, X2, P, G, w1, w2, meta, self.hidden_dim, self.out_dim, self._heads(),
-                            ACT[self.activation], mode)
+                            ACT[self.activation], mode, state)
 
 
 class NieFineCoattention(_FinePlanMixin, nn.Module):

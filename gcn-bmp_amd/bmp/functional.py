@@ -7,6 +7,8 @@ in bmp/ggnn.py etc., so parameter gradients come back in the reference layout.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -292,10 +294,11 @@ class GGNNStepFn(Function):
         return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None, None
 
 
-def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o):
+def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o, st=None):
     """The readout forward: one kernel per tile when the shape allows (WTp = pack_k4(WT), made here if not given),
     else row GEMM + segment sum.  Returns (ij, g)."""
     L = _lib.lib()
+    st = stream() if st is None else st
     N, d = h.shape
     d0 = 0 if h0 is None else h0.shape[1]
     ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
@@ -304,10 +307,10 @@ def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o):
         if WTp is None:
             WTp = pack_k4(WT)
         check(L.bmp_readout_tile_fwd(ptr(h), ptr(h0), pb.n_tiles, d, ptr(WTp), ptr(b), act_j, ptr(pb.row_w), ptr(pb.row_mol),
-                                     ptr(pb.mol_nrows), ptr(ij), ptr(g), stream()), "bmp_readout_tile_fwd")
+                                     ptr(pb.mol_nrows), ptr(ij), ptr(g), st), "bmp_readout_tile_fwd")
     else:
         check(L.bmp_readout_fwd(ptr(h), ptr(h0), pb.n_tiles, d, d0, o, ptr(WT), ptr(b), act_j, ptr(pb.row_w),
-                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), stream()), "bmp_readout_fwd")
+                                ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(ij), ptr(g), st), "bmp_readout_fwd")
     return ij, g
 
 
@@ -434,6 +437,9 @@ def _first_write(state, key) -> bool:
     return nb % nf == 0
 
 
+_RO_OFF_CHAIN = os.environ.get("BMP_READOUT_OFF_CHAIN", "1") != "0"        # A/B switch of PReadoutFn's off_chain form
+
+
 def _on_side(state, keep, launch) -> None:
     """Weight-gradient launches of the planned path: nothing in the backward chain reads their outputs (the plan's gradient
     buffers, folded into the flat gradient by LayoutPlan.collect), so they may run beside the chain.  With a side stream in
@@ -534,19 +540,32 @@ class PStepFn(Function):
 
 
 class PReadoutFn(Function):
-    """ReadoutFn on prepared weights.  W: WT, b, Wnat; G: dWT, db."""
+    """ReadoutFn on prepared weights.  W: WT, b, Wnat; G: dWT, db.
+
+    ``off_chain``: the caller knows that nothing reads the molecule vectors (the fine co-attention family ignores g_1 / g_2,
+    nie_coattention.py:335-370, while the encoder computes them all the same, train_binary.py:91-96).  With a side stream in
+    the plan's state the readout then runs there, beside the co-attention; its output is complete once the streams have
+    joined (LayoutPlan.collect / prepare) and must not be differentiated."""
 
     @staticmethod
-    def forward(ctx, h, h0, pb, W, G, act_j, state):
+    def forward(ctx, h, h0, pb, W, G, act_j, state, off_chain=False):
         L = _lib.lib()
         require_rows(h, "readout: h")
         _check_pb(pb, h)
         N, d = h.shape
         d0 = 0 if h0 is None else h0.shape[1]
         ctx.state = state
-        _register(state, "ro")
         WT = W["WT"]
         o = WT.shape[1] // 2
+        side = state.get("side") if (off_chain and state is not None and _RO_OFF_CHAIN) else None
+        ctx.off_chain = side is not None
+        if side is not None:
+            side.stream.wait_stream(torch.cuda.current_stream())
+            ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o, side.handle)
+            side.keep.append((h, h0, ij, g))
+            state["side_used"] = True
+            return g
+        _register(state, "ro")
         ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o)
         ctx.save_for_backward(h, ij, *([h0] if h0 is not None else []))
         ctx.pb, ctx.W, ctx.G, ctx.act_j, ctx.o = pb, W, G, act_j, o
@@ -555,6 +574,9 @@ class PReadoutFn(Function):
     @staticmethod
     def backward(ctx, dg):
         L = _lib.lib()
+        if ctx.off_chain:
+            raise RuntimeError("readout: the molecule vectors were declared unused (off_chain) and computed beside the chain; "
+                               "they cannot be differentiated")
         sv = ctx.saved_tensors
         h, ij = sv[0], sv[1]
         h0 = sv[2] if len(sv) > 2 else None
@@ -571,7 +593,7 @@ class PReadoutFn(Function):
                                 ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0),
                                 ptr(G["dWT"]), ptr(G.get("db")), acc, ptr(ws), nws, stream(),
                                 _side_handle(ctx.state, (h, h0, ws))), "bmp_readout_bwd")
-        return dh, dh0, None, None, None, None, None
+        return dh, dh0, None, None, None, None, None, None
 
 
 class PGRUFn(Function):

@@ -372,7 +372,8 @@ class GGNN(nn.Module):
                 h = Fn.PGRUFn.apply(h, m, pb, Wg, Gg, state, f"gru_{mode}", step == 0)
             self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
             return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
-                                       dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state)
+                                       dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
+                                       getattr(self, "_readout_off_chain", False))
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
                      b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])
@@ -381,7 +382,8 @@ class GGNN(nn.Module):
             h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0)
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
-                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state)
+                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
+                                   getattr(self, "_readout_off_chain", False))
 
     def forward(self, atom_array, adj=None):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``

@@ -49,7 +49,13 @@ class GraphConvPredictorForPair(nn.Module):
         return g1, g2, at1, at2, (0, 0)
 
     def forward(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
-        g1, g2, at1, at2, mol0 = self._encode(atoms_1, adjs_1, atoms_2, adjs_2)
+        # A co-attention of the fine family replaces the encoder's molecule vectors without reading them (:96 with
+        # nie_coattention.py:335-370): the readout is computed all the same, but a planned encoder may take it off the chain
+        self.graph_conv._readout_off_chain = bool(getattr(self.attn, "ignores_graph_vectors", False))
+        try:
+            g1, g2, at1, at2, mol0 = self._encode(atoms_1, adjs_1, atoms_2, adjs_2)
+        finally:
+            self.graph_conv._readout_off_chain = False
         if self.attn is not None:
             g1, g2 = self.attn(at1, g1, at2, g2, mol0=mol0)                  # train_binary.py:96
         self.g1, self.g2 = g1, g2

@@ -212,7 +212,7 @@ class RelGCN(nn.Module):
             x = Fn.PMsgFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
         self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")), dict(dWT=G["ro.dWT"]),
-                                   Fn.ACT["tanh"], state)
+                                   Fn.ACT["tanh"], state, getattr(self, "_readout_off_chain", False))
 
     def forward(self, h, adj=None):
         """models/relgcn.py:61-73."""

@@ -791,7 +791,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
                                   const float* wa2, const float* Q2, const float* Z1, const float* Z2, const float* Cbuf,
                                   const float* H1, const float* H2, const float* al1, const float* al2, float* dX1,
                                   float* dX2, float* dWbT, float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws,
-                                  size_t ws_floats, hipStream_t st) {
+                                  size_t ws_floats, hipStream_t st, hipStream_t st_w) {
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
     BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && n32 + n64 + n96 + n128 == B);
     BMP_REQUIRE(ws_floats >= bmp_coattn_nie_bwd_ws_floats(n_tiles1, n_tiles2, d, o, H, B));
@@ -840,6 +840,8 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
             off += cnt[c];
         }
     }
+    if (!st_w) st_w = st;
+    if ((rc = bmp_fork_to(st, st_w))) return rc;        // dQ2, dZ1, dZ2, dpart are complete: the weight gradients may start
     {   // dX1 += dZ1 . ZW1 (K = ZC) ; dX2 = dQ2 . W + dZ2 . ZW2 : one launch
         RGArgs g[2]; memset(g, 0, sizeof(g));
         g[0].s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};
@@ -856,11 +858,11 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
                              WGArgs{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0, dzb, 0, nullptr},
                              WGArgs{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb + ((mode & 2) ? ZC : 0), (mode & 2) ? 0 : 1, nullptr}};
         if (d <= 128 && d >= 64 && ZC >= 64) {
-            if ((rc = bmp_launch_wgrad_multi(g, 3, slab, st))) return rc;
+            if ((rc = bmp_launch_wgrad_multi(g, 3, slab, st_w))) return rc;
         } else {
             for (int p = 0; p < 3; ++p)
-                if ((rc = bmp_launch_wgrad(g[p], slab, st))) return rc;
+                if ((rc = bmp_launch_wgrad(g[p], slab, st_w))) return rc;
         }
     }
-    return bmp_launch_colsum(dpart, 2 * H + 1, B, 2 * H + 1, dwa, 0, slab, st);
+    return bmp_launch_colsum(dpart, 2 * H + 1, B, 2 * H + 1, dwa, 0, slab, st_w);
 }

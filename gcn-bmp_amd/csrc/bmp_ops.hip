@@ -120,19 +120,6 @@ extern "C" size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out) {
 }
 
 // Wnat [d_out x 4*d_in] = WT^T ; Ws [d_out x d_in] = WsT^T (reference Linear layout).
-// The weight-gradient launches of a backward entry point may go to a stream of their own (st_w; null or == st: in line):
-// nothing downstream in the chain reads them.  st_w picks up after everything st has been given so far.
-static int fork_to(hipStream_t st, hipStream_t st_w) {
-    if (!st_w || st_w == st) return 0;
-    hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) return (int)e;
-    e = hipEventRecord(ev, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st_w, ev, 0);
-    (void)hipEventDestroy(ev);                      // released once the record has completed
-    return (int)e;
-}
-
 extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ldo, int act, const float* x, int ldx,
                            int n_tiles, int d_in, int d_out, const int* csrT_ptr, const int* csrT_col,
                            const float* csrT_val, const float* Wnat, const float* Ws, const float* agg, const float* wdeg,
@@ -158,7 +145,7 @@ extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ld
     }
     int rc;
     if (!st_w) st_w = st;
-    if ((rc = fork_to(st, st_w))) return rc;        // dpre is complete: the weight gradients may start
+    if ((rc = bmp_fork_to(st, st_w))) return rc;        // dpre is complete: the weight gradients may start
     // dagg = dpre . Wnat
     {
         RGArgs a = rg_zero();
@@ -272,7 +259,7 @@ extern "C" int bmp_gru_bwd(const float* dhout, const float* h, const float* m, c
         if ((rc = bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GRU_DRH, st))) return rc;
     }
     if (!st_w) st_w = st;
-    if ((rc = fork_to(st, st_w))) return rc;        // da is complete: the weight gradients may start
+    if ((rc = bmp_fork_to(st, st_w))) return rc;        // da is complete: the weight gradients may start
     {   // [dh | dm] = da . A ; dh += dhacc
         RGArgs a = rg_zero();
         a.s[0] = RGSrc{da, nullptr, A, 3 * d, 0, 2 * d, 3 * d};
@@ -455,7 +442,7 @@ extern "C" int bmp_readout_bwd(const float* dg, const float* h, const float* h0,
     int rc;
     const int acc = accumulate_w ? 1 : 0;
     if (!st_w) st_w = st;
-    if ((rc = fork_to(st, st_w))) return rc;        // dij is complete
+    if ((rc = bmp_fork_to(st, st_w))) return rc;        // dij is complete
     {   // [dh | dh0] = dij . Wnat
         RGArgs a = rg_zero();
         a.s[0] = RGSrc{dij, nullptr, Wnat, 2 * o, 0, d + d0, 2 * o};
