@@ -217,7 +217,7 @@ class LayoutPlan:
         else:       # host form of the same table walk (tests of the tables without a GPU)
             self.prep.copy_(gather_sum_host(flat.detach(), self.tab_p_host))
         if self.state.get("side_used"):              # a backward whose gradients nobody collected
-            self.side.join()
+            self.state["side"].join()
         self.state = {"side": self.side} if self.side is not None else {}
         self.gk.zero_()          # a buffer no backward kernel writes this step (an unused readout, ...) must read as zero
 
@@ -225,7 +225,7 @@ class LayoutPlan:
         """One launch: flat_grad[j] += the parameter gradients folded out of the kernels' buffers."""
         if flat_grad.is_cuda:
             if self.state.get("side_used"):          # the side stream's weight gradients land in gk
-                self.side.join()
+                self.state["side"].join()
                 self.state["side_used"] = False
             check(_lib.lib().bmp_gather_sum(ptr(flat_grad), self.n_flat, ptr(self.gk), ptr(self.tab_g), self.Kg, 1,
                                             stream()), "bmp_gather_sum(collect)")

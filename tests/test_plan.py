@@ -173,3 +173,81 @@ def test_graphed_training_steps_equal_eager_steps():
     assert np.allclose(l_eager, l_graph, rtol=1e-5, atol=1e-6), (l_eager, l_graph)
     assert (p_eager - p_graph).abs().max().item() <= 1e-5 * p_eager.abs().max().item()
     assert l_eager[-1] < l_eager[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoder,hidden,attn", [("ggnn", 64, "nie"), ("relgcn", 64, "nie"), ("ggnn", 40, None)])
+def test_side_stream_step_is_bit_identical_to_the_one_stream_step(encoder, hidden, attn):
+    """The weight-gradient launches of the planned backward go to a low-priority side stream (bmp/plan.py SideStream; fused
+    step / layer kernels at hidden 64, the bmp_gru_bwd / bmp_msg_bwd / bmp_readout_bwd stream_w form at hidden 40): same
+    launches, same order inside every gradient buffer -> the same bits as with everything in line on one stream."""
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(60, seed=5, n_lo=4, n_hi=50, n_mean=18)
+    ms = packed.MolStore(store)
+    i1, i2 = np.arange(0, 24), np.arange(24, 48)
+    pb = packed.pack_from_store(ms, [i1, i2], device=dev)
+    t = (torch.arange(24, device=dev) % 2).int().view(-1, 1)
+    torch.manual_seed(2)
+    model = build_pair_predictor(hidden_dim=hidden, out_dim=hidden, n_layers=3, attn=attn, head=4, encoder=encoder).to(dev)
+    opt = FlatAdam(model, alpha=0.0)
+    outs = []
+    for side_on in (True, False, True):
+        y = opt.functional_forward(pb)
+        assert opt.plan is not None and opt.plan.side is not None
+        if not side_on:
+            saved, opt.plan.side = opt.plan.side, None
+            y = opt.functional_forward(pb)          # prepare() again: the step's state must not carry the stream
+        model.loss(y, t).backward()
+        used = bool(opt.plan.state.get("side_used"))
+        opt.collect_grads()
+        if not side_on:
+            opt.plan.side = saved
+        assert used == side_on
+        outs.append((y.detach().clone(), opt.grad.clone()))
+    torch.cuda.synchronize()
+    for y, g in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(g, outs[0][1])
+    assert outs[0][1].abs().max().item() > 0
+
+
+@pytest.mark.gpu
+def test_readout_taken_off_the_chain_still_gives_the_molecule_vectors():
+    """A fine co-attention never reads g_1 / g_2 (nie_coattention.py:335-370): the pair predictor tells a planned encoder,
+    which then computes its readout beside the chain.  After the join the vectors are the eager encoder's; differentiating
+    them is an error, not a silent zero."""
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(40, seed=7, n_lo=4, n_hi=40, n_mean=14)
+    ms = packed.MolStore(store)
+    pb = packed.pack_from_store(ms, [np.arange(0, 16), np.arange(16, 32)], device=dev)
+    torch.manual_seed(3)
+    model = build_pair_predictor(hidden_dim=64, out_dim=64, n_layers=2, attn="nie", head=4).to(dev)
+    with torch.no_grad():
+        g_eager = model.graph_conv(pb).clone()
+    opt = FlatAdam(model, alpha=0.0)
+    seen = {}
+    enc_forward = model.graph_conv.forward
+
+    def spy(*a, **k):
+        seen["g"] = enc_forward(*a, **k)
+        seen["off"] = model.graph_conv._readout_off_chain
+        return seen["g"]
+    model.graph_conv.forward = spy
+    try:
+        y = opt.functional_forward(pb)
+    finally:
+        model.graph_conv.forward = enc_forward
+    assert seen["off"] is True and opt.plan.state.get("side_used")
+    opt.plan.side.join()
+    torch.cuda.synchronize()
+    assert torch.equal(seen["g"].detach(), g_eager)
+    with pytest.raises(RuntimeError, match="off_chain"):
+        seen["g"].sum().backward(retain_graph=True)
+    y.sum().backward()                      # the chain itself is unaffected
+    opt.collect_grads()
+    assert torch.isfinite(opt.grad).all()
