@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end, batch-32 and roofline legs")
+    ap.add_argument("--host-profile", action="store_true", help="diagnostic: cProfile of the end-to-end epoch's host side to stderr")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -284,7 +285,14 @@ def main():
             body(i)
         host_ms.clear()
         dstore.plan_seconds, dstore.plan_calls = 0.0, 0
+        if args.host_profile:
+            import cProfile, pstats
+            prof = cProfile.Profile()
+            prof.enable()
         dt_e, _ = timed(steps_per_epoch, body)
+        if args.host_profile:
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
         e2e = dict(value=round(gb * steps_per_epoch / dt_e, 1), unit="pairs/s", steps=steps_per_epoch,
                    ms_per_step=round(1e3 * dt_e / steps_per_epoch, 3), ratio_to_resident=round(gb * steps_per_epoch / dt_e / value, 4),
                    host_plan_ms_per_batch=round(1e3 * dstore.plan_seconds / max(dstore.plan_calls, 1), 3),

@@ -146,7 +146,15 @@ def ptr(t: torch.Tensor | None):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Handle of torch's current stream on the current device (every launch asks: the raw accessor costs a fraction of a
+    microsecond, torch.cuda.current_stream() ten)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

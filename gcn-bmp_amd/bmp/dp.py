@@ -115,11 +115,32 @@ class FlatAdam:
             for prefix, mod in self._plan_sections:
                 mod._fast = (plan.P[prefix], plan.G[prefix], plan.state, tape)
                 hooked.append(mod)
+        # The views stand in for the parameters during the call -- what torch.func.functional_call does, without its
+        # per-call walk over the module tree (0.3 ms of host time per step; the RelGCN step is 1.5 ms): every registration
+        # of every parameter (tied ones included) was located once.
+        slots = self._param_slots()
         try:
-            return torch.func.functional_call(self.module, dict(zip(self.names, views)), args, kwargs)
+            for (reg, key, _orig), k in slots:
+                reg[key] = views[k]
+            return self.module(*args, **kwargs)
         finally:
+            for (reg, key, orig), _k in slots:
+                reg[key] = orig
             for mod in hooked:
                 mod._fast = None
+
+    def _param_slots(self):
+        """[((module._parameters, name, parameter), index into self.params)] over every registration of a flattened
+        parameter in the module tree."""
+        if getattr(self, "_slots", None) is None:
+            index = {id(p): k for k, p in enumerate(self.params)}
+            slots = []
+            for mod in self.module.modules():
+                for key, prm in mod._parameters.items():
+                    if prm is not None and id(prm) in index:
+                        slots.append(((mod._parameters, key, prm), index[id(prm)]))
+            self._slots = slots
+        return self._slots
 
     def _layout_plan(self):
         """bmp.plan.LayoutPlan over the sub-modules that support it (GGNN encoder, fine co-attention), built at the

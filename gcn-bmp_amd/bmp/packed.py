@@ -29,6 +29,7 @@ form in tests/test_packed.py.
 """
 from __future__ import annotations
 
+import os
 import time as _time
 from ctypes import c_void_p as _c_void_p
 from dataclasses import dataclass, field
@@ -493,6 +494,11 @@ class DeviceMolStore:
             self._stage = [None] * self.N_STAGE
             self._events = [None] * self.N_STAGE
             self._k = 0
+            # the batch's copy + emit kernel run on a stream of their own, so that batch i+1 is written while step i still
+            # computes (the host runs ahead); the caller's stream picks up behind them.  BMP_COLLATE_STREAM=0: in line
+            self.stream = torch.cuda.Stream(device=self.device) if os.environ.get("BMP_COLLATE_STREAM", "1") != "0" else None
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream(self.device))          # the store's upload above
 
     def _staging(self, n_ints: int) -> torch.Tensor:
         k = self._k
@@ -548,12 +554,15 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
     dstore.plan_seconds += _time.perf_counter() - t_plan          # the host's share of the collate (size arithmetic)
     dstore.plan_calls += 1
     n_up = n_tab + n_meta + n_lab
-    up = torch.empty(n_up, dtype=torch.int32, device=dev)
-    up.copy_(st[:n_up], non_blocking=True)
-    dstore._staged()
     N = n_tiles * R
-    ibuf = torch.empty(4 * N + 2 + 2 * E, dtype=torch.int32, device=dev)
-    fbuf = torch.empty(N + 2 * E, dtype=torch.float32, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    cs = dstore.stream if dstore.stream is not None else cur
+    with torch.cuda.stream(cs):
+        up = torch.empty(n_up, dtype=torch.int32, device=dev)
+        up.copy_(st[:n_up], non_blocking=True)
+        dstore._staged()
+        ibuf = torch.empty(4 * N + 2 + 2 * E, dtype=torch.int32, device=dev)
+        fbuf = torch.empty(N + 2 * E, dtype=torch.float32, device=dev)
     atom_id, csr_ptr, csr_col = ibuf[:N], ibuf[N:2 * N + 1], ibuf[2 * N + 1:2 * N + 1 + E]
     o = 2 * N + 1 + E
     csrT_ptr, csrT_col, row_mol = ibuf[o:o + N + 1], ibuf[o + N + 1:o + N + 1 + E], ibuf[o + N + 1 + E:o + 2 * N + 1 + E]
@@ -562,7 +571,11 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
     d = dstore.dev
     check(L.bmp_collate_emit(ptr(up), I, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(d[5]), ptr(d[6]),
                              ptr(atom_id), ptr(row_w), ptr(row_mol), ptr(csr_ptr), ptr(csr_col), ptr(csr_val), ptr(csrT_ptr),
-                             ptr(csrT_col), ptr(csrT_val), stream()), "bmp_collate_emit")
+                             ptr(csrT_col), ptr(csrT_val), _c_void_p(cs.cuda_stream)), "bmp_collate_emit")
+    if cs is not cur:
+        for t in (up, ibuf, fbuf):          # allocated on the collate stream, read by the caller's: no reuse before that work
+            t.record_stream(cur)
+        cur.wait_stream(cs)
     nrows_host = st_np[I:2 * I].astype(np.int64)
     pb = PackedMolBatch(
         R=R, n_tiles=n_tiles, n_mols=I, atom_id=atom_id, row_w=row_w, csr_ptr=csr_ptr, csr_col=csr_col, csr_val=csr_val,
