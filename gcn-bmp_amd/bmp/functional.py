@@ -238,7 +238,7 @@ class GGNNStepFn(Function):
         UcTp = _cached(cache, ("f", UcT.data_ptr()), lambda: pack_k4(UcT))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
-        check(L.bmp_ggnn_step_fwd(ptr(h), pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+        check(L.bmp_ggnn_step_fwd(ptr(h), 0, pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                   ptr(WTp), ptr(bE), ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout),
                                   stream()), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, WT, AT, UcT, m, rz, c)
@@ -437,6 +437,35 @@ def _first_write(state, key) -> bool:
     return nb % nf == 0
 
 
+def _at(t: torch.Tensor, row: int):
+    """Device pointer of row ``row`` of a contiguous 1-D / 2-D tensor."""
+    return _lib.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
+
+
+def _fwd_parts(state, pb):
+    """[(tile0, n_tiles, stream handle)] for a tile-local forward launch of the planned encoder.  A step / layer reads and
+    writes only its own tile's rows (molecules never straddle tiles), so the two halves of the batch -- the two sides of a
+    pair batch -- can advance as two chains on two streams: a launch of 455 tiles on 256 CUs leaves its second round
+    0.78 full, two chains of 228 and 227 tiles keep more of them busy (C2 3.00 -> 2.96 ms; four chains on four streams: 3.7-4.0
+    ms, not adopted).  Call AFTER the launch's outputs are allocated:
+    the second stream is ordered behind everything the current one holds at that moment (whatever used those blocks
+    before), and the encoder joins the two before anything reads whole arrays (``_join_parts``)."""
+    sp = state.get("split") if state is not None else None
+    T = pb.n_tiles
+    if sp is None or T < 64:
+        return ((0, T, stream()),)
+    T0 = pb.side_tiles[1] if (len(pb.side_tiles) == 3 and 0 < pb.side_tiles[1] < T) else T // 2
+    sp.stream.wait_stream(torch.cuda.current_stream())
+    state["split_open"] = True
+    return ((0, T0, stream()), (T0, T - T0, sp.handle))
+
+
+def _join_parts(state) -> None:
+    if state is not None and state.get("split_open"):
+        state["split"].join()
+        state["split_open"] = False
+
+
 _RO_OFF_CHAIN = os.environ.get("BMP_READOUT_OFF_CHAIN", "1") != "0"        # A/B switch of PReadoutFn's off_chain form
 
 
@@ -507,9 +536,10 @@ class PStepFn(Function):
         N, d = h.shape
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
-        check(L.bmp_ggnn_step_fwd(ptr(h), pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
-                                  ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
-                                  ptr(c), ptr(hout), stream()), "bmp_ggnn_step_fwd")
+        for t0, nt, st in _fwd_parts(state, pb):
+            check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+                                      ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
+                                      ptr(c), ptr(hout), st), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
         _register(state, gkey)
@@ -609,8 +639,11 @@ class PGRUFn(Function):
         N, d = h.shape
         f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=h.device)
         rz, c, hout = f(N, 2 * d), f(N, d), f(N, d)
-        check(L.bmp_gru_fwd(ptr(h), ptr(m), pb.n_tiles, d, int(first), ptr(W["AT"]), ptr(W["UcT"]), ptr(W["b"]), ptr(rz), ptr(c),
-                            ptr(hout), stream()), "bmp_gru_fwd")
+        R = pb.R
+        for t0, nt, st in _fwd_parts(state, pb):          # row-wise: a tile range is a pointer offset
+            r0 = t0 * R
+            check(L.bmp_gru_fwd(_at(h, r0), _at(m, r0), nt, d, int(first), ptr(W["AT"]), ptr(W["UcT"]), ptr(W["b"]), _at(rz, r0),
+                                _at(c, r0), _at(hout, r0), st), "bmp_gru_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
         _register(state, gkey)
@@ -645,9 +678,15 @@ class PMsgFn(Function):
         N = x.shape[0]
         f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=x.device)
         agg, wdeg, out = f(N, 4 * d_in), f(N, 4), f(N, d_out)
-        check(L.bmp_msg_fwd(ptr(x), d_in, pb.n_tiles, d_in, d_out, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
-                            ptr(W["WT"]), ptr(W["bE"]), ptr(W.get("WsT")), ptr(W.get("bs")), act, ptr(agg), ptr(wdeg), ptr(out),
-                            d_out, stream()), "bmp_msg_fwd")
+        # Without a self connection x is only the gather's source, addressed by the absolute row numbers of the CSR: a tile
+        # range is then an offset into the row pointers and the outputs (the entries they index stay where they are).
+        parts = _fwd_parts(state, pb) if W.get("WsT") is None else ((0, pb.n_tiles, stream()),)
+        R = pb.R
+        for t0, nt, st in parts:
+            r0 = t0 * R
+            check(L.bmp_msg_fwd(ptr(x), d_in, nt, d_in, d_out, _at(pb.csr_ptr, r0), ptr(pb.csr_col), ptr(pb.csr_val),
+                                ptr(W["WT"]), ptr(W["bE"]), ptr(W.get("WsT")), ptr(W.get("bs")), act, _at(agg, r0), _at(wdeg, r0),
+                                _at(out, r0), d_out, st), "bmp_msg_fwd")
         ctx.save_for_backward(x, agg, wdeg, out)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
         _register(state, gkey)
@@ -676,13 +715,14 @@ def rel_layer_supported(d_in: int, d_out: int) -> bool:
     return bool(_lib.lib().bmp_relgcn_layer_supported(int(d_in), int(d_out)))
 
 
-def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act):
+def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None):
     L = _lib.lib()
     N, d = x.shape
     out = torch.empty(N, d, dtype=torch.float32, device=x.device)
     wdeg = torch.empty(N, 4, dtype=torch.float32, device=x.device)
-    check(L.bmp_relgcn_layer_fwd(ptr(x), pb.n_tiles, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
-                                 ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), stream()), "bmp_relgcn_layer_fwd")
+    for t0, nt, st in _fwd_parts(state, pb):
+        check(L.bmp_relgcn_layer_fwd(ptr(x), t0, nt, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
+                                     ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), st), "bmp_relgcn_layer_fwd")
     return out, wdeg
 
 
@@ -738,7 +778,7 @@ class PRelLayerFn(Function):
     def forward(ctx, x, pb, W, G, state, gkey, act):
         require_rows(x, "relgcn layer: x")
         _check_pb(pb, x)
-        out, wdeg = _rel_fwd(x, pb, W["WTp"], W["bE"], W["WsTp"], W["bs"], act)
+        out, wdeg = _rel_fwd(x, pb, W["WTp"], W["bE"], W["WsTp"], W["bs"], act, state)
         ctx.save_for_backward(x, out, wdeg)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
         _register(state, gkey)

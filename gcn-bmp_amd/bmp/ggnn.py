@@ -370,6 +370,7 @@ class GGNN(nn.Module):
                 Wg = dict(AT=P[f"gru_{mode}.AT"], UcT=P["gru.UcT"], b=P[f"gru_{mode}.b"], A=P[f"gru_{mode}.A"], Uc=P["gru.Uc"])
                 Gg = dict(dAT=G[f"gru_{mode}.dAT"], dUcT=G[f"gru_{mode}.dUcT"], db=G[f"gru_{mode}.db"])
                 h = Fn.PGRUFn.apply(h, m, pb, Wg, Gg, state, f"gru_{mode}", step == 0)
+            Fn._join_parts(state)             # the steps ran as two chains of tiles
             self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
             return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
                                        dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
@@ -380,6 +381,7 @@ class GGNN(nn.Module):
             g = f"g{li}_{mode}"
             Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
             h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0)
+        Fn._join_parts(state)                 # the steps ran as two chains of tiles: whole arrays are read from here on
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
                                    dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,

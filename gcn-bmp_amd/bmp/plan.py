@@ -110,6 +110,19 @@ class SideStream:
             pass
 
 
+class PartStream:
+    """An ordinary stream for the second half of the planned encoder's tile-local forward launches
+    (functional._fwd_parts)."""
+
+    def __init__(self, device):
+        import ctypes
+        self.stream = torch.cuda.Stream(device=torch.device(device))
+        self.handle = ctypes.c_void_p(self.stream.cuda_stream)
+
+    def join(self) -> None:
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class LayoutPlan:
     """Built for a list of (prefix, module) pairs whose parameters are slices of one flat fp32 buffer.
     A module takes part if it defines ``prepared_layouts()``, ``primary_layouts()``, ``gk_spec()`` and
@@ -154,6 +167,8 @@ class LayoutPlan:
         # weight-gradient launches beside the backward chain (functional._on_side); BMP_WGRAD_STREAM=0 keeps them in line
         self.side = SideStream(device) if (torch.device(device).type == "cuda"
                                            and os.environ.get("BMP_WGRAD_STREAM", "1") != "0") else None
+        self.split = PartStream(device) if (torch.device(device).type == "cuda"
+                                            and os.environ.get("BMP_FWD_SPLIT", "1") != "0") else None
         self.state: Dict[str, dict] = {}
         self._views()
 
@@ -218,12 +233,21 @@ class LayoutPlan:
             self.prep.copy_(gather_sum_host(flat.detach(), self.tab_p_host))
         if self.state.get("side_used"):              # a backward whose gradients nobody collected
             self.state["side"].join()
-        self.state = {"side": self.side} if self.side is not None else {}
+        if self.state.get("split_open"):
+            self.state["split"].join()
+        self.state = {}
+        if self.side is not None:
+            self.state["side"] = self.side
+        if self.split is not None:
+            self.state["split"] = self.split
         self.gk.zero_()          # a buffer no backward kernel writes this step (an unused readout, ...) must read as zero
 
     def collect(self, flat_grad: torch.Tensor) -> None:
         """One launch: flat_grad[j] += the parameter gradients folded out of the kernels' buffers."""
         if flat_grad.is_cuda:
+            if self.state.get("split_open"):
+                self.state["split"].join()
+                self.state["split_open"] = False
             if self.state.get("side_used"):          # the side stream's weight gradients land in gk
                 self.state["side"].join()
                 self.state["side_used"] = False

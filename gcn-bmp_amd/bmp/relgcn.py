@@ -209,7 +209,9 @@ class RelGCN(nn.Module):
                 continue
             W = {k: P[f"c{l}.{k}"] for k in ("WT", "bE", "WsT", "bs", "Wnat", "Ws")}
             Gl = {k: G[f"c{l}.{k}"] for k in ("dWT", "dbE", "dWsT", "dbs")}
+            Fn._join_parts(state)             # an unfused layer reads whole arrays
             x = Fn.PMsgFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
+        Fn._join_parts(state)                 # fused layers ran as two chains of tiles
         self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")), dict(dWT=G["ro.dWT"]),
                                    Fn.ACT["tanh"], state, getattr(self, "_readout_off_chain", False))

@@ -20,6 +20,7 @@
 struct StepArgs {
     // graph
     const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
+    int tile0;                      // the launch covers tiles tile0 .. tile0 + gridDim.x - 1 (all arrays whole)
     int first;
     // forward
     const float* h;                 // [N x D] step input
@@ -256,11 +257,12 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * FZ_R;
+    const int tile = blockIdx.x + a.tile0;
+    const int row0 = tile * FZ_R;
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;         // this lane's row for reg 0 of row block 0
-    const int rot = (blockIdx.x * 8) % D;
+    const int rot = (tile * 8) % D;
     const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
     const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
     float* Hl = Hs + lrow * LD + col;        // accumulator-layout views of the two LDS tiles
@@ -412,11 +414,12 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * FZ_R;
+    const int tile = blockIdx.x + a.tile0;
+    const int row0 = tile * FZ_R;
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
-    const int rot = (blockIdx.x * 8) % D;
+    const int rot = (tile * 8) % D;
     const float* Xw = Xs + (wrow0 + l31) * LD + 4 * hi;
     const float* Yw = Ys + (wrow0 + l31) * LD + 4 * hi;
     float* Xl = Xs + lrow * LD + col;
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct RelArgs {
     const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
+    int tile0;                      // the launch covers tiles tile0 .. tile0 + gridDim.x - 1 (all arrays whole)
     int act;
     // forward
     const float* h;                 // [N x D]
@@ -591,11 +595,12 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * FZ_R;
+    const int tile = blockIdx.x + a.tile0;
+    const int row0 = tile * FZ_R;
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
-    const int rot = (blockIdx.x * 8) % D;
+    const int rot = (tile * 8) % D;
     const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
     const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
 
@@ -669,11 +674,12 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int row0 = blockIdx.x * FZ_R;
+    const int tile = blockIdx.x + a.tile0;
+    const int row0 = tile * FZ_R;
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
-    const int rot = (blockIdx.x * 8) % D;
+    const int rot = (tile * 8) % D;
     const float* Xw = Xs + (wrow0 + l31) * LD + 4 * hi;
     const float* Yw = Ys + (wrow0 + l31) * LD + 4 * hi;
     float* Yl = Ys + lrow * LD + col;
@@ -875,12 +881,12 @@ static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
 
 // One GGNN propagation step, forward (models/ggnn.py:215-263): m = message(h), h' = GRU([h, m]).
 // Weight layouts as bmp_msg_fwd / bmp_gru_fwd.  Saves m [N x d], rz [N x 2d], c [N x d].
-extern "C" int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
-                                 const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
-                                 const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
-    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr,
+                                 const int* csr_col, const float* csr_val, const float* WT, const float* bE, const float* AT,
+                                 const float* UcT, const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
+    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
@@ -988,12 +994,12 @@ static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
 
 // out = act(h . WsT + bs + sum_e gather_e(h) . WT_e + wdeg_e * bE_e); WT [4d x d] and WsT [d x d] K4-packed
 // (bmp/functional.py:pack_k4).  Saves wdeg [N x 4].
-extern "C" int bmp_relgcn_layer_fwd(const float* h, int n_tiles, int d, const int* csr_ptr, const int* csr_col,
+extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col,
                                     const float* csr_val, const float* WT, const float* bE, const float* WsT, const float* bs,
                                     int act, float* out, float* wdeg, hipStream_t st) {
-    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
     RelArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act; a.tile0 = tile0;
     a.h = h; a.WT = WT; a.bE = bE; a.WsT = WsT; a.bs = bs; a.out = out; a.wdeg = wdeg;
     return d == 128 ? rel_launch<128>(false, a, n_tiles, st) : rel_launch<64>(false, a, n_tiles, st);
 }

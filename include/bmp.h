@@ -113,8 +113,10 @@ int bmp_gru_state_bwd(const float* dsout, const float* hd, const float* m, const
  * 0..d-1), o2 [d x 3d] = m^T.da (dAT rows d..2d-1), dUcT [d x d], cs [7d] = column sums (dbE | db); all of it is ONE
  * GEMM launch + ONE fixed-order reduction.  first != 0 (the GRU's first call after reset has no r gate): the da_r columns
  * of gda are neither written by bwd nor read by wgrad and count as zeros. */
+/* The forward launches take a tile range: tiles tile0 .. tile0 + n_tiles - 1 of the WHOLE arrays passed (a step is
+ * tile-local: molecules never straddle tiles), so that two halves of a batch can run as two chains on two streams. */
 int bmp_ggnn_step_supported(int d);
-int bmp_ggnn_step_fwd(const float* h, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
+int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
                       const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
                       const float* b, float* m, float* rz, float* c, float* hout, bmp_stream_t stream);
 int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
@@ -134,7 +136,7 @@ int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const f
  * wgrad: o1 [d x 5d] = h^T.gda (cols [0,4d): dWT as [k][e*d+c]; cols [4d,5d): dWsT), dbE [4 x d] = wdeg^T.dpre,
  * cs [5d] = column sums of gda (cs[4d:] = dbs). */
 int bmp_relgcn_layer_supported(int d_in, int d_out);
-int bmp_relgcn_layer_fwd(const float* h, int n_tiles, int d, const int* csr_ptr, const int* csr_col, const float* csr_val,
+int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col, const float* csr_val,
                          const float* WT, const float* bE, const float* WsT, const float* bs, int act, float* out,
                          float* wdeg, bmp_stream_t stream);
 int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
