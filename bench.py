@@ -324,13 +324,14 @@ def main():
         key = (ctypes.c_int * cap)(); cnt = (ctypes.c_int * cap)()
         ms_ = (ctypes.c_double * cap)(); fl = (ctypes.c_double * cap)(); by = (ctypes.c_double * cap)()
         # In the timed region the weight-gradient launches run on a low-priority side stream beside the backward chain
-        # (bmp/plan.py SideStream) and share the CUs with it: an event pair around such a launch then spans the sharing, not the
-        # kernel.  The per-kernel figures are taken with every launch in line on one stream (what BMP_WGRAD_STREAM=0 runs).
+        # (bmp/plan.py SideStream) and the encoder's forward as two chains of tiles on two streams (PartStream): launches
+        # share the CUs, and an event pair around one then spans the sharing, not the kernel.  The per-kernel figures are
+        # taken with every launch whole and in line on one stream (what BMP_ONE_STREAM=1 runs).
         plan = getattr(opt, "plan", None)
-        side_saved = getattr(plan, "side", None)
+        side_saved, split_saved = getattr(plan, "side", None), getattr(plan, "split", None)
         if plan is not None:
             torch.cuda.synchronize()
-            plan.side = None
+            plan.side = plan.split = None
         L.bmp_prof_start(-1)
         t0p = time.perf_counter()
         for i in range(n_prof):
@@ -339,7 +340,7 @@ def main():
         inline_ms = 1e3 * (time.perf_counter() - t0p) / n_prof
         nk = L.bmp_prof_collect(key, cnt, ms_, fl, by, cap)
         if plan is not None:
-            plan.side = side_saved
+            plan.side, plan.split = side_saved, split_saved
         rows_prof = sum(batches[i % len(batches)][0].n_rows for i in range(n_prof))
         real_frac = sum(batches[i % len(batches)][0].n_real_atoms for i in range(n_prof)) / rows_prof
         kern = {key[i]: dict(launches=cnt[i] / n_prof, ms=ms_[i] / n_prof, flops=fl[i] / n_prof) for i in range(nk)}
@@ -377,10 +378,11 @@ def main():
                         per_kernel_ms_per_step={KERNEL_NAMES.get(k, str(k)): round(v["ms"], 4) for k, v in
                                                 sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
                         measured=f"HIP events around every launch of every instrumented kernel, {n_prof} steps after the timed "
-                                 "region, each on its launch stream, with the weight-gradient side stream switched off for these "
-                                 "steps so that no two launches share the CUs (the events' own cost makes such a step "
+                                 "region, each on its launch stream, with the side stream and the two-chain forward switched off for "
+                                 "these steps so that no two launches share the CUs (the events' own cost makes such a step "
                                  f"{inline_ms:.2f} ms); achieved = algorithmic flops (real atoms only) / event time",
-                        side_stream="on in the timed region" if side_saved is not None else "off")
+                        streams="side stream (weight gradients) and two forward chains on in the timed region"
+                        if side_saved is not None else "one stream")
 
     cpu = cpu_more = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

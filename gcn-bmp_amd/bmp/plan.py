@@ -165,9 +165,10 @@ class LayoutPlan:
         self.gk = torch.zeros(max(gk_off, 1), dtype=torch.float32, device=device)
         # weight-gradient launches beside the backward chain (functional._on_side): BMP_WGRAD_STREAM=0 keeps them in line
         # weight-gradient launches beside the backward chain (functional._on_side); BMP_WGRAD_STREAM=0 keeps them in line
-        self.side = SideStream(device) if (torch.device(device).type == "cuda"
+        one = os.environ.get("BMP_ONE_STREAM") == "1"        # profiling: every launch in line on the caller's stream
+        self.side = SideStream(device) if (torch.device(device).type == "cuda" and not one
                                            and os.environ.get("BMP_WGRAD_STREAM", "1") != "0") else None
-        self.split = PartStream(device) if (torch.device(device).type == "cuda"
+        self.split = PartStream(device) if (torch.device(device).type == "cuda" and not one
                                             and os.environ.get("BMP_FWD_SPLIT", "1") != "0") else None
         self.state: Dict[str, dict] = {}
         self._views()

@@ -1,25 +1,26 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 4"
-# kernel stats with every launch in line on one stream (BMP_WGRAD_STREAM=0): a kernel's duration is its own.  In the default
-# run the weight-gradient launches share the CUs with the backward chain (low-priority side stream) and their traced
-# durations span the sharing: that trace is kept for C2 as *_overlapped.csv
-export BMP_WGRAD_STREAM=0
+# kernel stats with every launch whole and in line on one stream (BMP_ONE_STREAM=1): a kernel's duration is its own.  In the
+# default run the weight-gradient launches share the CUs with the backward chain (low-priority side stream), the forward
+# runs as two chains of tiles, and traced durations span the sharing: that trace is kept for C2 as *_overlapped.csv
+export BMP_ONE_STREAM=1
 for c in c2 c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$c -- $B --config $c > gpurun_out/ks_$c.log 2>&1
   python tools/summarize_prof.py gpurun_out/ks_$c gpurun_out/r02_${c}_kernel_stats.csv 34 > /dev/null
   rm -rf gpurun_out/ks_$c
 done
-unset BMP_WGRAD_STREAM
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_o -- $B --config c2 > gpurun_out/ks_o.log 2>&1
-python tools/summarize_prof.py gpurun_out/ks_o gpurun_out/r02_c2_kernel_stats_overlapped.csv 34 > /dev/null
-rm -rf gpurun_out/ks_o
+# counter passes: whole launches too (per-launch counters next to the roofline leg's per-launch figures)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- $B > gpurun_out/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- $B > gpurun_out/pmc_w.log 2>&1
 python tools/summarize_pmc.py gpurun_out/r02_c2_pmc_hbm_traffic.json gpurun_out/pmc_f gpurun_out/pmc_w > /dev/null
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d gpurun_out/pmc_s -- $B > gpurun_out/pmc_s.log 2>&1
 python tools/summarize_pmc.py gpurun_out/r02_c2_pmc_sq.json gpurun_out/pmc_s > /dev/null
 rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s
+unset BMP_ONE_STREAM
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_o -- $B --config c2 > gpurun_out/ks_o.log 2>&1
+python tools/summarize_prof.py gpurun_out/ks_o gpurun_out/r02_c2_kernel_stats_overlapped.csv 34 > /dev/null
+rm -rf gpurun_out/ks_o
 ls gpurun_out | grep r02_
 for c in c2 c3 c4; do
   python bench.py --config $c > gpurun_out/r02_bench_$c.json 2> gpurun_out/r02_bench_$c.err

@@ -8,8 +8,8 @@ path = sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(dst, "w") as f:
-    mode = ("BMP_WGRAD_STREAM=0 (every launch in line on one stream)" if os.environ.get("BMP_WGRAD_STREAM") == "0"
-            else "default (weight-gradient launches on the low-priority side stream, sharing the CUs with the backward chain)")
+    mode = ("BMP_ONE_STREAM=1 (every launch whole and in line on one stream)" if os.environ.get("BMP_ONE_STREAM") == "1"
+            else "default (weight-gradient launches on the low-priority side stream, forward as two chains of tiles: launches share the CUs)")
     f.write(f"# source: rocprofv3 --kernel-trace --stats -- python bench.py ... ; {mode}; kernel names shortened\n")
     f.write("name,calls,total_ms,avg_us,percent" + (",ms_per_step" if steps else "") + "\n")
     for r in rows[:40]:
