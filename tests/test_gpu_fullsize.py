@@ -132,3 +132,44 @@ def test_full_size_step_is_bitwise_reproducible(world):
         outs.append((y.detach().clone(), opt.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][1].abs().max().item() > 0
+
+
+def test_many_steps_with_all_streams_match_the_one_stream_run(world, monkeypatch):
+    """Twelve end-to-end training steps (device collate on its own stream, weight gradients on the low-priority side stream,
+    readout beside the chain, forward as two chains of tiles, Adam) against the same steps with every launch in line on one
+    stream: bit-identical parameters at the end -- what a race between iterations (a buffer handed back too early, a missing
+    join) would break."""
+    from bmp import packed
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict
+    w = world
+    rs = np.random.RandomState(11)
+    perm = [rs.permutation(len(w["i1"])) for _ in range(3)]
+
+    def run(one_stream):
+        monkeypatch.setenv("BMP_ONE_STREAM", "1" if one_stream else "0")
+        monkeypatch.setenv("BMP_COLLATE_STREAM", "0" if one_stream else "1")
+        model = build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, attn="nie", head=8).to(w["dev"])
+        load_param_dict(model, w["p"])
+        ds = packed.DeviceMolStore(w["ms"], w["dev"])
+        opt = FlatAdam(model, alpha=1e-3)
+        losses = []
+        for it in range(12):
+            p = perm[it % 3]
+            sl = slice((it % 4) * 256, (it % 4) * 256 + 256)
+            pb, t = packed.pack_from_store_device(ds, [w["i1"][p][sl], w["i2"][p][sl]], labels=w["lab"][p][sl].reshape(-1, 1))
+            y = opt.functional_forward(pb)
+            loss = model.loss(y, t)
+            loss.backward()
+            opt.collect_grads()
+            opt.step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize()
+        assert (opt.plan.side is None) == one_stream and (ds.stream is None) == one_stream
+        return opt.flat.clone(), torch.stack(losses)
+
+    p_multi, l_multi = run(False)
+    p_one, l_one = run(True)
+    assert torch.equal(l_multi, l_one) and torch.equal(p_multi, p_one)
+    assert torch.isfinite(p_one).all() and (l_one[-1] < l_one[0]).item()
