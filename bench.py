@@ -307,7 +307,13 @@ def main():
             for i in range(10):
                 body(i)
             n32 = 300
+            if args.host_profile:
+                prof = cProfile.Profile()
+                prof.enable()
             dt_32, _ = timed(n32, lambda i: body(i + 1))
+            if args.host_profile:
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
             b32 = dict(value=round(32 * n32 / dt_32, 1), unit="pairs/s", steps=n32, ms_per_step=round(1e3 * dt_32 / n32, 3),
                        what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end")
 
