@@ -435,3 +435,60 @@ def test_gru_with_separate_state_fwd_bwd():
     assert rel(o.detach(), out.detach()) < 1e-5
     for name, a, w in zip("hd m s WT UrzT UcT b".split(), got, ref):
         assert rel(a.grad, w.grad) < 1e-5, name
+
+
+def test_step_and_layer_forward_over_tile_ranges_equal_the_whole_launch(fn, batch):
+    """bmp_ggnn_step_fwd / bmp_relgcn_layer_fwd over two tile ranges of the whole arrays (tile0 argument: the two chains of the
+    planned encoder's forward) write exactly what one launch over all tiles writes -- a step is tile-local."""
+    from bmp import _lib
+    from bmp._lib import check, ptr, stream
+    from bmp.functional import pack_k4
+    L = _lib.lib()
+    _, _, _, pb = batch
+    pbd = to_dev(pb)
+    d, N, T = 128, pb.n_rows, pb.n_tiles
+    assert T >= 3
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: (0.2 * torch.randn(*s, generator=g)).to(dev())
+    h = r(N, d)
+    WTp, bE, ATp, UcTp, b = pack_k4(r(4 * d, d)), r(4, d), pack_k4(r(2 * d, 3 * d)), pack_k4(r(d, d)), r(3 * d)
+    WsTp, bs = pack_k4(r(d, d)), r(d)
+    f = lambda *s: torch.full(s, float("nan"), device=dev())
+
+    def step(ranges):
+        m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
+        for t0, nt in ranges:
+            check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, 0, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), ptr(WTp), ptr(bE),
+                                      ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout), stream()), "step")
+        return m, rz, c, hout
+
+    def layer(ranges):
+        out, wdeg = f(N, d), f(N, 4)
+        for t0, nt in ranges:
+            check(L.bmp_relgcn_layer_fwd(ptr(h), t0, nt, d, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), ptr(WTp), ptr(bE),
+                                         ptr(WsTp), ptr(bs), 2, ptr(out), ptr(wdeg), stream()), "layer")
+        return out, wdeg
+
+    for run in (step, layer):
+        whole = run([(0, T)])
+        parts = run([(T // 3, T - T // 3), (0, T // 3)])
+        for a, bb in zip(whole, parts):
+            assert torch.isfinite(a).all() and torch.equal(a, bb)
+
+
+def test_low_priority_stream_entry_points():
+    """bmp_stream_create_low / bmp_stream_destroy: a usable stream handle of the device's lowest priority."""
+    import ctypes
+    from bmp import _lib
+    from bmp._lib import check
+    L = _lib.lib()
+    hnd = ctypes.c_void_p()
+    check(L.bmp_stream_create_low(ctypes.byref(hnd)), "bmp_stream_create_low")
+    assert hnd.value
+    s = torch.cuda.ExternalStream(hnd.value, device=dev())
+    with torch.cuda.stream(s):
+        x = torch.ones(1024, device=dev()) * 3
+    s.synchronize()
+    assert float(x.sum()) == 3072.0
+    check(L.bmp_stream_destroy(hnd), "bmp_stream_destroy")
+    assert L.bmp_stream_create_low(None) != 0
