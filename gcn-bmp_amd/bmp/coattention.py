@@ -148,7 +148,7 @@ class NieCoattnFn(Function):
                                    ptr(wa2),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
-                                   stream(), None), "bmp_coattn_nie_bwd")
+                                   stream(), None, None, None), "bmp_coattn_nie_bwd")
         return (dX1, dX2, dWbT, dZW1T, dZW2T, dzb, dwa[:H], dwa[H:2 * H], dwa[2 * H:], None, None, None, None, None,
                 None, None, None)
 
@@ -158,10 +158,11 @@ class PNieFn(Function):
     G: dWbT, dZW1T, dZW2T, dzb, dwa."""
 
     @staticmethod
-    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode, state=None):
+    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode, state=None, rm1=None, rm2=None):
         L = _lib.lib()
         dev = X1.device
         ctx.state = state
+        ctx.rm = (rm1, rm2) if (rm1 is not None and rm2 is not None) else (None, None)      # row -> molecule maps (dead rows)
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         ZC = L.bmp_coattn_zcols(o, H)
         ctx.joint = X2 is None          # one row tensor for both sides: its gradient comes back as ONE tensor too
@@ -206,10 +207,11 @@ class PNieFn(Function):
                                    ptr(W["ZW2"]), ptr(W["wa1"]), ptr(W["wa2"]),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(G["dWbT"]), ptr(G["dZW1T"]), ptr(G["dZW2T"]), ptr(G["dzb"]), ptr(G["dwa"]),
-                                   ptr(ws), nws, stream(), _side_handle(ctx.state, (X1, X2, ws))), "bmp_coattn_nie_bwd")
+                                   ptr(ws), nws, stream(), _side_handle(ctx.state, (X1, X2, ws)), ptr(ctx.rm[0]), ptr(ctx.rm[1])),
+              "bmp_coattn_nie_bwd")
         if ctx.joint:
-            return dX, None, None, None, None, None, None, None, None, None, None, None, None
-        return dX1, dX2, None, None, None, None, None, None, None, None, None, None, None
+            return (dX,) + (None,) * 14
+        return (dX1, dX2) + (None,) * 13
 
 
 class _FinePlanMixin:
@@ -243,10 +245,14 @@ class _FinePlanMixin:
     def _forward_fast(self, atoms_1, atoms_2, fast, mode):
         P, G, state, _tape = fast
         X1, X2, w1, w2, meta, joint = pair_rows(atoms_1, atoms_2)
+        rm1, rm2 = atoms_1.pb.row_mol, atoms_2.pb.row_mol
         if joint:
+            n1 = X1.shape[0]
             X1, X2 = atoms_1.rows, None
+            if rm1 is not None:
+                rm1, rm2 = rm1[:n1], rm1[n1:]
         return PNieFn.apply(X1, X2, P, G, w1, w2, meta, self.hidden_dim, self.out_dim, self._heads(),
-                            ACT[self.activation], mode, state)
+                            ACT[self.activation], mode, state, rm1, rm2)
 
 
 class NieFineCoattention(_FinePlanMixin, nn.Module):

@@ -64,7 +64,7 @@ class PairFeatFn(Function):
 
 def _tail(layers, l_out, h):
     ls = list(layers) + [l_out]
-    return MLPFn.apply(None, h, None, None, *[l.W for l in ls], *[l.b for l in ls])
+    return MLPFn.apply(None, h, None, None, None, *[l.W for l in ls], *[l.b for l in ls])
 
 
 def _check_act(activation):

@@ -26,7 +26,7 @@ class MLPFn(Function):
     autograd when given; ``tape`` is the plan's dummy differentiable input."""
 
     @staticmethod
-    def forward(ctx, tape, x1, x2, G, *wb):
+    def forward(ctx, tape, x1, x2, G, state, *wb):
         from . import _lib
         from ._lib import check, ptr, stream
         L = _lib.lib()
@@ -42,7 +42,7 @@ class MLPFn(Function):
         acts = [torch.empty(B, n, dtype=torch.float32, device=x1.device) for n in dims[1:]]
         check(L.bmp_mlp_fwd(ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(bs), _parr(acts), stream()), "bmp_mlp_fwd")
         ctx.save_for_backward(x1, *( [x2] if x2 is not None else [] ), *Ws, *acts)
-        ctx.meta = (nl, dims, x2 is not None, [b is not None for b in bs], G)
+        ctx.meta = (nl, dims, x2 is not None, [b is not None for b in bs], G, state)
         return acts[-1]
 
     @staticmethod
@@ -50,7 +50,7 @@ class MLPFn(Function):
         from . import _lib
         from ._lib import check, ptr, stream
         L = _lib.lib()
-        nl, dims, has2, has_b, G = ctx.meta
+        nl, dims, has2, has_b, G, state = ctx.meta
         sv = list(ctx.saved_tensors)
         x1 = sv.pop(0)
         x2 = sv.pop(0) if has2 else None
@@ -70,11 +70,13 @@ class MLPFn(Function):
             db = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) if has_b[l] else None for l, w in enumerate(Ws)]
         nws = L.bmp_mlp_bwd_ws_floats(B, nl, cd)
         ws = torch.empty(max(nws, 4), dtype=torch.float32, device=dev)
+        from .functional import _side_handle
+        st_w = _side_handle(state, (ws,)) if G is not None else None       # the partials' fold beside the chain (planned path)
         check(L.bmp_mlp_bwd(ptr(dy), ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(acts), ptr(dx1), ptr(dx2),
-                            _parr(dW), _parr(db), ptr(ws), nws, stream()), "bmp_mlp_bwd")
+                            _parr(dW), _parr(db), ptr(ws), nws, stream(), st_w), "bmp_mlp_bwd")
         if G is not None:
-            return (None, dx1, dx2, None) + (None,) * (2 * nl)
-        return (None, dx1, dx2, None) + tuple(dW) + tuple(db)
+            return (None, dx1, dx2, None, None) + (None,) * (2 * nl)
+        return (None, dx1, dx2, None, None) + tuple(dW) + tuple(db)
 
 
 class SCEFn(Function):
@@ -182,10 +184,10 @@ class MLP(nn.Module):
         if x.is_cuda and self._kernel_ok():
             fast = getattr(self, "_fast", None)
             if fast is not None:
-                P, G, _state, tape = fast
+                P, G, state, tape = fast
                 wb = [P[f"W{k}"] for k in range(len(ls))] + [P[f"b{k}"] for k in range(len(ls))]
-                return MLPFn.apply(tape, x, x2, G, *wb)
-            return MLPFn.apply(None, x, x2, None, *[l.W for l in ls], *[l.b for l in ls])
+                return MLPFn.apply(tape, x, x2, G, state, *wb)
+            return MLPFn.apply(None, x, x2, None, None, *[l.W for l in ls], *[l.b for l in ls])
         h = x if x2 is None else torch.cat((x, x2), dim=-1)
         for l in self.layers:                                   # models/mlp.py:42-43
             h = self.activation(torch.nn.functional.linear(h, l.W, l.b))

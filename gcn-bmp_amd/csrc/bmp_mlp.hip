@@ -4,6 +4,7 @@
 // framework ops was ~40 launches of a few microseconds each per step.  Plain fp32 FMA, fixed summation orders.
 #include <string.h>
 #include "bmp_common.h"
+#include "bmp_kernels.h"
 
 #define MLP_MAXL 4          // Linear layers
 #define MLP_MAXW 64         // widest hidden / output layer
@@ -213,7 +214,7 @@ extern "C" size_t bmp_mlp_bwd_ws_floats(int B, int nl, const int* dims) {
 // Backward from dy [B x dims[nl]]: dx1, dx2, and per layer dW[l], db[l] (HOST arrays of device pointers; db[l] may be NULL).
 extern "C" int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
                            const float* const* W, float* const* act, float* dx1, float* dx2, float* const* dW,
-                           float* const* db, float* ws, size_t ws_floats, hipStream_t st) {
+                           float* const* db, float* ws, size_t ws_floats, hipStream_t st, hipStream_t st_w) {
     MlpArgs a;
     int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, nullptr, act);
     if (rc) return rc;
@@ -230,7 +231,10 @@ extern "C" int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float
     a.dy = dy; a.dx1 = dx1; a.dx2 = dx2; a.slab = ws; a.slab_stride = off;
     hipLaunchKernelGGL(k_mlp_bwd, dim3(nwg), dim3(256), 0, st, a);
     BMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 63) / 64), dim3(256), 0, st, r);
+    // the fold of the per-workgroup weight-gradient partials is off the backward chain: stream_w (bmp.h, "stream_w")
+    if (!st_w) st_w = st;
+    if ((rc = bmp_fork_to(st, st_w))) return rc;
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 63) / 64), dim3(256), 0, st_w, r);
     BMP_LAUNCH_CHECK();
     return 0;
 }

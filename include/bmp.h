@@ -47,7 +47,7 @@ int bmp_prof_collect(int* key, int* count, double* ms, double* flops, double* by
 /* A stream of the device's lowest priority for launches that run beside a dependent chain (no reference counterpart:
  * chainer runs one stream).  The backward's weight-gradient GEMMs go there: nothing in the chain reads their output, and
  * their workgroups fill the CUs the tile kernels' last round leaves idle.  Destroy with bmp_stream_destroy. */
-/* bmp_msg_bwd, bmp_gru_bwd, bmp_readout_bwd and bmp_coattn_nie_bwd take that stream as `stream_w` (NULL or == stream: everything in line):
+/* bmp_msg_bwd, bmp_gru_bwd, bmp_readout_bwd, bmp_coattn_nie_bwd and bmp_mlp_bwd take that stream as `stream_w` (NULL or == stream: everything in line):
  * their weight-gradient launches go there, ordered behind what `stream` has been given up to the point inside the call
  * where their operands are complete.  The workspace `ws` is then read on both streams: the caller keeps it (and the row
  * tensors) alive until the two streams have joined.  accumulate_w != 0: the weight gradients add into their outputs (the
@@ -230,7 +230,7 @@ int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, 
                        const float* Q2, const float* Z1, const float* Z2, const float* Cbuf, const float* H1,
                        const float* H2, const float* al1, const float* al2, float* dX1, float* dX2, float* dWbT,
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
-                       bmp_stream_t stream, bmp_stream_t stream_w);
+                       bmp_stream_t stream, bmp_stream_t stream_w, const int* row_mol1, const int* row_mol2);
 
 /* ---- BiMPM matching -- models/coattention/bimpm.py:45-199 with aggr = F.sum (train_binary.py:253-256) ----
  * mol_1, mol_2 [B x 3H] for B drug pairs: max-pooling matching, attentive-mean matching and attentive-max matching of every
@@ -293,7 +293,7 @@ int bmp_mlp_fwd(const float* x1, int d1, const float* x2, int d2, int B, int nl,
 size_t bmp_mlp_bwd_ws_floats(int B, int nl, const int* dims);
 int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
                 const float* const* W, float* const* act, float* dx1, float* dx2, float* const* dW, float* const* db,
-                float* ws, size_t ws_floats, bmp_stream_t stream);
+                float* ws, size_t ws_floats, bmp_stream_t stream, bmp_stream_t stream_w);
 int bmp_sce_fwd(const float* y, const int* t, int n, float* loss, float* sums, bmp_stream_t stream);
 int bmp_sce_bwd(const float* y, const int* t, int n, const float* sums, const float* gout, float* dy, bmp_stream_t stream);
 

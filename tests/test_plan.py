@@ -251,3 +251,35 @@ def test_readout_taken_off_the_chain_still_gives_the_molecule_vectors():
     y.sum().backward()                      # the chain itself is unaffected
     opt.collect_grads()
     assert torch.isfinite(opt.grad).all()
+
+
+@pytest.mark.gpu
+def test_coattention_backward_clears_what_its_pair_kernels_do_not_write():
+    """bmp_coattn_nie_bwd with the packed batches' row -> molecule maps clears only the dead rows and the padding columns of
+    its work arrays (instead of filling all of them): with the allocator's free blocks poisoned with NaN beforehand, the
+    planned gradients are still the eager ones."""
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(60, seed=9, n_lo=4, n_hi=60, n_mean=20)
+    ms = packed.MolStore(store)
+    ds = packed.DeviceMolStore(ms, dev)
+    i1, i2 = np.arange(0, 30), np.arange(30, 60)
+    pb = packed.pack_from_store_device(ds, [i1, i2])
+    assert pb.row_mol is not None and int((pb.row_mol < 0).sum()) > 0          # there are dead rows to clear
+    t = (torch.arange(30, device=dev) % 2).int().view(-1, 1)
+    torch.manual_seed(4)
+    model = build_pair_predictor(hidden_dim=64, out_dim=64, n_layers=2, attn="nie", head=4).to(dev)
+    y = model(pb)
+    model.loss(y, t).backward()
+    eager = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()]).clone()
+    opt = FlatAdam(model, alpha=0.0)
+    for _ in range(2):
+        poison = [torch.full((n,), float("nan"), device=dev) for n in (1 << 22, 1 << 20, 1 << 18, 1 << 16, 1 << 14)]
+        del poison                                                   # back to the allocator, NaN inside
+        y2 = opt.functional_forward(pb)
+        model.loss(y2, t).backward()
+        opt.collect_grads()
+        assert torch.isfinite(opt.grad).all()
+        assert (opt.grad - eager).abs().max().item() <= 1e-5 * eager.abs().max().item()
