@@ -161,10 +161,14 @@ class FlatAdam:
 
     def collect_grads(self) -> None:
         g = self._leaf.grad
-        self.grad = g if g is not None else torch.zeros_like(self.flat)
         self._leaf = None
         if self.plan is not None:
-            self.plan.collect(self.grad)            # one launch: += the planned modules' parameter gradients
+            # one launch: (+)= the planned modules' parameter gradients; when autograd carried none (every parameter is the
+            # plan's), that launch writes the whole buffer and no zero-fill precedes it
+            self.grad = g if g is not None else torch.empty_like(self.flat)
+            self.plan.collect(self.grad, overwrite=g is None)
+        else:
+            self.grad = g if g is not None else torch.zeros_like(self.flat)
 
     def reattach(self) -> None:
         """Fold any .grad tensor that autograd (or a caller) replaced back into the flat buffer."""

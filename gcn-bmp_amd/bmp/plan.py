@@ -243,8 +243,9 @@ class LayoutPlan:
             self.state["split"] = self.split
         self.gk.zero_()          # a buffer no backward kernel writes this step (an unused readout, ...) must read as zero
 
-    def collect(self, flat_grad: torch.Tensor) -> None:
-        """One launch: flat_grad[j] += the parameter gradients folded out of the kernels' buffers."""
+    def collect(self, flat_grad: torch.Tensor, overwrite: bool = False) -> None:
+        """One launch: flat_grad[j] += the parameter gradients folded out of the kernels' buffers (``overwrite``: = instead
+        of +=, zeros where the plan has nothing: for a gradient buffer that holds nothing yet)."""
         if flat_grad.is_cuda:
             if self.state.get("split_open"):
                 self.state["split"].join()
@@ -252,8 +253,10 @@ class LayoutPlan:
             if self.state.get("side_used"):          # the side stream's weight gradients land in gk
                 self.state["side"].join()
                 self.state["side_used"] = False
-            check(_lib.lib().bmp_gather_sum(ptr(flat_grad), self.n_flat, ptr(self.gk), ptr(self.tab_g), self.Kg, 1,
-                                            stream()), "bmp_gather_sum(collect)")
+            check(_lib.lib().bmp_gather_sum(ptr(flat_grad), self.n_flat, ptr(self.gk), ptr(self.tab_g), self.Kg,
+                                            0 if overwrite else 1, stream()), "bmp_gather_sum(collect)")
+        elif overwrite:
+            flat_grad.copy_(gather_sum_host(self.gk, self.tab_g_host))
         else:
             flat_grad.add_(gather_sum_host(self.gk, self.tab_g_host))
 

@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_o -- $B --
 python tools/summarize_prof.py gpurun_out/ks_o gpurun_out/r02_c2_kernel_stats_overlapped.csv 34 > /dev/null
 rm -rf gpurun_out/ks_o
 ls gpurun_out | grep r02_
+cp gpurun_out/r02_c2_pmc_hbm_traffic.json profiles/      # the bench quotes `traffic` from the file of ITS library version
 for c in c2 c3 c4; do
   python bench.py --config $c > gpurun_out/r02_bench_$c.json 2> gpurun_out/r02_bench_$c.err
 done
