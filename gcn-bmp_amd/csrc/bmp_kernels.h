@@ -116,14 +116,16 @@ struct BmpProfScope {
 
 // The weight-gradient launches of a backward entry point may go to a stream of their own (st_w; null or == st: in line):
 // nothing downstream in the chain reads them.  st_w picks up after everything st has been given so far.
-static inline int bmp_fork_to(hipStream_t st, hipStream_t st_w) {
-    if (!st_w || st_w == st) return 0;
+// (bmp_stream_after: `to` picks up behind what `from` holds now; a null handle there is the device's default stream.)
+static inline int bmp_stream_after(hipStream_t from, hipStream_t to) {
+    if (to == from) return 0;
     hipEvent_t ev;
     hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) return (int)e;
-    e = hipEventRecord(ev, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st_w, ev, 0);
+    e = hipEventRecord(ev, from);
+    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
     (void)hipEventDestroy(ev);                      // released once the record has completed
     return (int)e;
 }
+static inline int bmp_fork_to(hipStream_t st, hipStream_t st_w) { return st_w ? bmp_stream_after(st, st_w) : 0; }
 

@@ -51,7 +51,9 @@ int bmp_prof_collect(int* key, int* count, double* ms, double* flops, double* by
  * their weight-gradient launches go there, ordered behind what `stream` has been given up to the point inside the call
  * where their operands are complete.  The workspace `ws` is then read on both streams: the caller keeps it (and the row
  * tensors) alive until the two streams have joined.  accumulate_w != 0: the weight gradients add into their outputs (the
- * later calls of a tied layer). */
+ * later calls of a tied layer).  bmp_coattn_nie_bwd launches its pair kernels once per size class of the drug pairs; a
+ * class of at most 64 pairs next to a more populated one also runs on `stream_w`, beside the other classes, and `stream`
+ * picks up behind it inside the call. */
 int bmp_stream_create_low(bmp_stream_t* out);
 int bmp_stream_destroy(bmp_stream_t stream);
 
