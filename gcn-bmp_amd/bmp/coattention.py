@@ -17,7 +17,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import check, ptr, stream
-from .functional import ACT, _side_handle, _ws
+from .functional import ACT, _side_handle, _ws, flush_deferred
 from .ggnn import Linear, PackedAtoms, as_packed_atoms
 
 
@@ -184,6 +184,7 @@ class PNieFn(Function):
                                    ptr(al1), ptr(al2), ptr(out1), ptr(out2), stream()), "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
         ctx.meta, ctx.dims, ctx.W, ctx.G = meta, (d, o, H, act, ZC, mode), W, G
+        flush_deferred(state)          # the readout the encoder held back: behind this call's launches in the queues
         return out1, out2
 
     @staticmethod

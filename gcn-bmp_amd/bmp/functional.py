@@ -294,15 +294,26 @@ class GGNNStepFn(Function):
         return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None, None
 
 
-def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o, st=None):
+def flush_deferred(state) -> None:
+    """Launch what PReadoutFn's off-chain form held back."""
+    if state is not None and state.get("deferred"):
+        todo, state["deferred"] = state["deferred"], []
+        for launch in todo:
+            launch()
+
+
+def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o, st=None, out=None):
     """The readout forward: one kernel per tile when the shape allows (WTp = pack_k4(WT), made here if not given),
     else row GEMM + segment sum.  Returns (ij, g)."""
     L = _lib.lib()
     st = stream() if st is None else st
     N, d = h.shape
     d0 = 0 if h0 is None else h0.shape[1]
-    ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
-    g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
+    if out is not None:
+        ij, g = out
+    else:
+        ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+        g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
     if pb.row_mol is not None and L.bmp_readout_tile_supported(d, d0, o):
         if WTp is None:
             WTp = pack_k4(WT)
@@ -466,6 +477,7 @@ def _join_parts(state) -> None:
         state["split_open"] = False
 
 
+_RO_DEFER = os.environ.get("BMP_READOUT_DEFER", "1") != "0"
 _RO_OFF_CHAIN = os.environ.get("BMP_READOUT_OFF_CHAIN", "1") != "0"        # A/B switch of PReadoutFn's off_chain form
 
 
@@ -590,10 +602,20 @@ class PReadoutFn(Function):
         side = state.get("side") if (off_chain and state is not None and _RO_OFF_CHAIN) else None
         ctx.off_chain = side is not None
         if side is not None:
-            side.stream.wait_stream(torch.cuda.current_stream())
-            ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o, side.handle)
-            side.keep.append((h, h0, ij, g))
-            state["side_used"] = True
+            # enqueued LATER (flush_deferred: once the co-attention's forward launches are in their queue): launched here,
+            # its 455 one-per-CU workgroups take the CUs before the chain's next launches get to them
+            ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+            g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
+
+            def launch():
+                side.stream.wait_stream(torch.cuda.current_stream())
+                _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o, side.handle, out=(ij, g))
+                side.keep.append((h, h0, ij, g))
+                state["side_used"] = True
+            if _RO_DEFER:
+                state.setdefault("deferred", []).append(launch)
+            else:
+                launch()
             return g
         _register(state, "ro")
         ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o)

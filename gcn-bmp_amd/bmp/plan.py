@@ -250,6 +250,9 @@ class LayoutPlan:
             if self.state.get("split_open"):
                 self.state["split"].join()
                 self.state["split_open"] = False
+            if self.state.get("deferred"):
+                from .functional import flush_deferred
+                flush_deferred(self.state)
             if self.state.get("side_used"):          # the side stream's weight gradients land in gk
                 self.state["side"].join()
                 self.state["side_used"] = False
