@@ -2,7 +2,8 @@
 """Headline benchmark: drug-pairs/sec, fwd+bwd(+Adam), binary-DDI GGNN d=128 + Nie co-attention.
 
     python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4]
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or bare: the process then
+     starts that launcher itself as a child, before it has imported torch, and exits with its code)
 
 A "step" is one training step over one batch of 1024 drug pairs per GPU: both molecules of every pair encoded, co-attention,
 link predictor, sigmoid cross entropy, backward, one gradient all-reduce (N > 1), Adam.  Every molecule INSTANCE is encoded
@@ -31,9 +32,39 @@ for _p in (ROOT, os.path.join(ROOT, "gcn-bmp_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np          # noqa: E402
-import torch                # noqa: E402
-import torch.distributed as dist   # noqa: E402
+np = torch = dist = None     # bound by _heavy_imports(): nothing below the self-launch check may run before it
+
+
+def _heavy_imports():
+    """numpy / torch are imported only AFTER main() has decided whether this process is the launcher of `--gpus N`
+    (self_launch): the launcher never loads the HIP runtime, let alone touches a device."""
+    global np, torch, dist
+    import numpy as _np
+    import torch as _torch
+    import torch.distributed as _dist
+    np, torch, dist = _np, _torch, _dist
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` without an outer torchrun (the form of the driver's N = 1 command): start the N ranks as
+    CHILD processes -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py
+    <same arguments>` -- relay their output (rank 0 prints the JSON line) and return the launcher's exit code.  This
+    process has not imported torch and never touches a GPU; nothing is re-exec'ed."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    port = int(env.get("BMP_BENCH_PORT") or _free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 HEAD = 8
 PAIRS_PER_GPU = 1024
@@ -155,11 +186,18 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # not under a launcher: become one (children do the work)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("BMP_BENCH_RANK_CHECK_ONLY") == "1":        # tests/test_bench_launch.py: the launch path without a GPU
+        print(json.dumps({"rank_check": True, "rank": rank, "local_rank": local_rank, "world": world,
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        return
+    _heavy_imports()
     # rehearsal switches for a one-GPU box (never set by the driver): all ranks on device 0, collectives over gloo
     one_device = os.environ.get("BMP_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("BMP_BENCH_BACKEND", "nccl")
@@ -411,6 +449,9 @@ def main():
             line["cpu_baseline_more"] = cpu_more
         if rank_ms:
             line["rank_ms_per_step"] = rank_ms
+        if world > 1 or force_pg:          # what the process group itself reports (not the command line)
+            line["dist"] = dict(world_size=dist.get_world_size(), backend=dist.get_backend(),
+                                launcher=os.environ.get("TORCHELASTIC_RUN_ID") is not None)
         print(json.dumps(line))
     if world > 1 or force_pg:
         dist.barrier()
