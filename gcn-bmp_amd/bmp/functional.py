@@ -453,14 +453,17 @@ def _at(t: torch.Tensor, row: int):
     return _lib.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
 
 
-def _fwd_parts(state, pb):
+def _fwd_parts(state, pb, keep=()):
     """[(tile0, n_tiles, stream handle)] for a tile-local forward launch of the planned encoder.  A step / layer reads and
     writes only its own tile's rows (molecules never straddle tiles), so the two halves of the batch -- the two sides of a
     pair batch -- can advance as two chains on two streams: a launch of 455 tiles on 256 CUs leaves its second round
     0.78 full, two chains of 228 and 227 tiles keep more of them busy (C2 3.00 -> 2.96 ms; four chains on four streams: 3.7-4.0
     ms, not adopted).  Call AFTER the launch's outputs are allocated:
     the second stream is ordered behind everything the current one holds at that moment (whatever used those blocks
-    before), and the encoder joins the two before anything reads whole arrays (``_join_parts``)."""
+    before), and the encoder joins the two before anything reads whole arrays (``_join_parts``).
+    ``keep``: every tensor the second stream's launch reads or writes.  They were allocated on the current stream, and under
+    ``torch.no_grad()`` nothing else holds them once the Function returns: the plan's state keeps them until the join, so the
+    caching allocator cannot hand their blocks to a later main-stream launch while the part stream still uses them."""
     sp = state.get("split") if state is not None else None
     T = pb.n_tiles
     if sp is None or T < 64:
@@ -468,6 +471,7 @@ def _fwd_parts(state, pb):
     T0 = pb.side_tiles[1] if (len(pb.side_tiles) == 3 and 0 < pb.side_tiles[1] < T) else T // 2
     sp.stream.wait_stream(torch.cuda.current_stream())
     state["split_open"] = True
+    state.setdefault("split_keep", []).append(keep)
     return ((0, T0, stream()), (T0, T - T0, sp.handle))
 
 
@@ -475,6 +479,7 @@ def _join_parts(state) -> None:
     if state is not None and state.get("split_open"):
         state["split"].join()
         state["split_open"] = False
+        state["split_keep"] = []
 
 
 _RO_DEFER = os.environ.get("BMP_READOUT_DEFER", "1") != "0"
@@ -548,7 +553,7 @@ class PStepFn(Function):
         N, d = h.shape
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
-        for t0, nt, st in _fwd_parts(state, pb):
+        for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                       ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
                                       ptr(c), ptr(hout), st), "bmp_ggnn_step_fwd")
@@ -662,7 +667,7 @@ class PGRUFn(Function):
         f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=h.device)
         rz, c, hout = f(N, 2 * d), f(N, d), f(N, d)
         R = pb.R
-        for t0, nt, st in _fwd_parts(state, pb):          # row-wise: a tile range is a pointer offset
+        for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):          # row-wise: a tile range is a pointer offset
             r0 = t0 * R
             check(L.bmp_gru_fwd(_at(h, r0), _at(m, r0), nt, d, int(first), ptr(W["AT"]), ptr(W["UcT"]), ptr(W["b"]), _at(rz, r0),
                                 _at(c, r0), _at(hout, r0), st), "bmp_gru_fwd")
@@ -702,7 +707,7 @@ class PMsgFn(Function):
         agg, wdeg, out = f(N, 4 * d_in), f(N, 4), f(N, d_out)
         # Without a self connection x is only the gather's source, addressed by the absolute row numbers of the CSR: a tile
         # range is then an offset into the row pointers and the outputs (the entries they index stay where they are).
-        parts = _fwd_parts(state, pb) if W.get("WsT") is None else ((0, pb.n_tiles, stream()),)
+        parts = _fwd_parts(state, pb, (x, agg, wdeg, out)) if W.get("WsT") is None else ((0, pb.n_tiles, stream()),)
         R = pb.R
         for t0, nt, st in parts:
             r0 = t0 * R
@@ -742,7 +747,7 @@ def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None):
     N, d = x.shape
     out = torch.empty(N, d, dtype=torch.float32, device=x.device)
     wdeg = torch.empty(N, 4, dtype=torch.float32, device=x.device)
-    for t0, nt, st in _fwd_parts(state, pb):
+    for t0, nt, st in _fwd_parts(state, pb, (x, out, wdeg)):
         check(L.bmp_relgcn_layer_fwd(ptr(x), t0, nt, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
                                      ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), st), "bmp_relgcn_layer_fwd")
     return out, wdeg

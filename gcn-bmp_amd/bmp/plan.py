@@ -163,7 +163,6 @@ class LayoutPlan:
         self.tab_g = torch.from_numpy(tab_g).to(device)
         self.prep = torch.empty(max(prep_off, 1), dtype=torch.float32, device=device)
         self.gk = torch.zeros(max(gk_off, 1), dtype=torch.float32, device=device)
-        # weight-gradient launches beside the backward chain (functional._on_side): BMP_WGRAD_STREAM=0 keeps them in line
         # weight-gradient launches beside the backward chain (functional._on_side); BMP_WGRAD_STREAM=0 keeps them in line
         one = os.environ.get("BMP_ONE_STREAM") == "1"        # profiling: every launch in line on the caller's stream
         self.side = SideStream(device) if (torch.device(device).type == "cuda" and not one
@@ -232,11 +231,14 @@ class LayoutPlan:
                   "bmp_gather_sum(prepare)")
         else:       # host form of the same table walk (tests of the tables without a GPU)
             self.prep.copy_(gather_sum_host(flat.detach(), self.tab_p_host))
+        if self.state.get("deferred"):               # a planned forward nobody collected (predict, an unplanned co-attention):
+            from .functional import flush_deferred   # the readout it held back still runs, its output is not left undefined
+            flush_deferred(self.state)
         if self.state.get("side_used"):              # a backward whose gradients nobody collected
             self.state["side"].join()
         if self.state.get("split_open"):
             self.state["split"].join()
-        self.state = {}
+        self.state = {}                              # (drops split_keep / the side stream's keep list: both streams are joined)
         if self.side is not None:
             self.state["side"] = self.side
         if self.split is not None:
@@ -250,6 +252,7 @@ class LayoutPlan:
             if self.state.get("split_open"):
                 self.state["split"].join()
                 self.state["split_open"] = False
+                self.state["split_keep"] = []
             if self.state.get("deferred"):
                 from .functional import flush_deferred
                 flush_deferred(self.state)

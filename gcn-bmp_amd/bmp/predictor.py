@@ -58,6 +58,10 @@ class GraphConvPredictorForPair(nn.Module):
             self.graph_conv._readout_off_chain = False
         if self.attn is not None:
             g1, g2 = self.attn(at1, g1, at2, g2, mol0=mol0)                  # train_binary.py:96
+        fast = getattr(self.graph_conv, "_fast", None)
+        if fast is not None:             # a co-attention off the planned path never flushed the readout the encoder held back
+            from .functional import flush_deferred
+            flush_deferred(fast[2])
         self.g1, self.g2 = g1, g2
         return self.mlp(g1, g2)          # MLP on [g1 | g2] :98-101 (no concatenation copy); NTN / HolE / ... :102-116
 
@@ -116,7 +120,7 @@ def build_pair_predictor(hidden_dim=128, out_dim=128, n_layers=4, weight_tying=T
         a = NieFineCoattention(hidden_dim=hidden_dim, out_dim=out_dim, head=head, activation="tanh")
     elif attn == "bimpm":                                                        # train_binary.py:253-256: head = fp_out_dim
         from .bimpm import BiMPM
-        a = BiMPM(hidden_dim=hidden_dim, out_dim=out_dim, head=head, with_max_pool=True, with_att_mean=True, with_att_max=True)
+        a = BiMPM(hidden_dim=hidden_dim, out_dim=out_dim, head=out_dim, with_max_pool=True, with_att_mean=True, with_att_max=True)
     elif attn in ("deep", "very-deep", "extreme-deep"):                         # train_binary.py:229-247
         from . import coattention as C
         cls = {"deep": C.DeepNieFineCoattention, "very-deep": C.VeryDeepNieFineCoattention,

@@ -222,6 +222,8 @@ def perceive_aromaticity(atoms: np.ndarray, bonds: np.ndarray) -> np.ndarray:
     for k, (a, b, t) in enumerate(bonds.tolist()):
         btype[(min(a, b), max(a, b))] = k
         nbrs[a].append((b, t)); nbrs[b].append((a, t))
+    bridge = _bridges(n, bonds.tolist())
+    ring_bond = {(min(a, b), max(a, b)) for k, (a, b, _t) in enumerate(bonds.tolist()) if not bridge[k]}
 
     def electrons(v: int) -> int:
         """pi electrons atom v brings to a ring it is part of; -1: the atom cannot be aromatic."""
@@ -233,11 +235,12 @@ def perceive_aromaticity(atoms: np.ndarray, bonds: np.ndarray) -> np.ndarray:
             return -1
         if doubles:
             w = doubles[0][0]
-            if in_ring[w]:
+            if (min(v, w), max(v, w)) in ring_bond:
                 return 1                                   # a ring double bond (this ring's or a fused neighbour's)
             if z == 6 and int(atoms[w]) in (7, 8, 16):
                 return 0                                   # exocyclic C=O / C=S / C=N: sp2 carbon with an empty p orbital
-            return -1
+            return -1                                      # exocyclic C=C (fulvene, an ylidene link between two rings): the
+                                                           # bond itself lies in no ring, whatever its far end belongs to
         if any(t == AROMATIC for _w, t in nbrs[v]):
             return -1                                      # already aromatic notation: leave such rings alone
         if z in _LONE_PAIR and len(nbrs[v]) <= 3:

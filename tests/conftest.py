@@ -16,3 +16,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionstart(session):
+    # achieved-error log of tests/parity_util.py: one file per session
+    log = os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl")
+    try:
+        os.remove(log)
+    except OSError:
+        pass
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        import parity_util
+        parity_util.summarize()
+    except Exception:
+        pass

@@ -85,3 +85,11 @@ def test_dropout_flag_is_accepted():
     assert enc.dropout_rate == 0.2
     with pytest.raises(ValueError):
         GGNN(out_dim=8, hidden_dim=16, dropout_rate=1.5)
+
+
+def test_bimpm_builder_takes_its_head_from_the_output_width():
+    """train_binary.py:253-256 builds BiMPM(head=fp_out_dim): the builder's generic ``head`` (8) is not BiMPM's."""
+    from bmp.predictor import build_pair_predictor
+    m = build_pair_predictor(hidden_dim=64, out_dim=16, n_layers=2, attn="bimpm")
+    assert m.attn.head == 16 and m.attn.out_dim == 3 * 16
+    assert tuple(m.mlp.layers[0].W.shape) == (32, 2 * 3 * 16)

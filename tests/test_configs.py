@@ -66,11 +66,7 @@ def test_c4_multilabel_d256_matches_oracle():
     ld = model.loss(yd, T(lab).to(dev))
     ld.backward()
 
-    def close(got, want, name, tol=1e-4):
-        got = got.detach().double().cpu(); want = want.detach()
-        scale = max(want.abs().max().item(), 1e-6)
-        err = (got - want).abs().max().item()
-        assert err <= tol * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+    from parity_util import close
     close(yd, y, "logits"); close(ld, loss, "loss")
     for name, gr in grad_dict(model).items():
         close(gr, p[name].grad, f"grad {name}")

@@ -9,11 +9,7 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
-def _close(got, want, name, tol=1e-4):
-    got = got.detach().double().cpu(); want = want.detach().double()
-    scale = max(want.abs().max().item(), 1e-6)
-    err = (got - want).abs().max().item()
-    assert err <= tol * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+from parity_util import close as _close      # asserts AND logs the achieved relative error
 
 
 @pytest.mark.parametrize("d,H,mb,N1,N2", [(32, 8, 5, 9, 13), (64, 16, 3, 33, 20), (128, 128, 2, 12, 7)])
@@ -62,7 +58,8 @@ def test_bimpm_pair_predictor_matches_oracle(form):
     y_o, _, _ = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn="bimpm")
     loss_o = O.sigmoid_cross_entropy(y_o, T(lab))
     loss_o.backward()
-    model = build_pair_predictor(hidden_dim=d, out_dim=H, n_layers=2, attn="bimpm", head=H).to(dev)
+    model = build_pair_predictor(hidden_dim=d, out_dim=H, n_layers=2, attn="bimpm").to(dev)      # builder default head = 8 ...
+    assert model.attn.head == H                                       # ... but BiMPM(head=fp_out_dim), train_binary.py:253-256
     assert model.mlp.layers[0].W.shape == (32, 2 * 3 * H)
     load_param_dict(model, p)
     if form == "two-sided":

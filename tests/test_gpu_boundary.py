@@ -10,11 +10,7 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
-def _close(got, want, name, tol=1e-4):
-    got = got.detach().double().cpu(); want = want.detach().double()
-    scale = max(want.abs().max().item(), 1e-6)
-    err = (got - want).abs().max().item()
-    assert err <= tol * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+from parity_util import close as _close      # asserts AND logs the achieved relative error
 
 
 @pytest.mark.parametrize("attn", ["nie", "pool", "parallel", "alternating", "global", "neural"])

@@ -34,9 +34,8 @@ def _run(dev, store, i1, i2, d=64, nl=2, attn="nie", tol=1e-4, encoder="ggnn"):
     model.loss(yd, label.to(dev)).backward()
 
     def close(got, want, name):
-        got = got.detach().double().cpu(); want = want.detach()
-        scale = max(want.abs().max().item(), 1e-6)
-        assert (got - want).abs().max().item() <= tol * scale, f"{name}: {(got - want).abs().max().item():.3e} / {scale:.3e}"
+        from parity_util import close as _c
+        _c(got, want, name, tol)
     close(yd, y, "logits")
     for name, gr in grad_dict(model).items():
         if p[name].grad is not None:

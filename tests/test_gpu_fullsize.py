@@ -173,3 +173,39 @@ def test_many_steps_with_all_streams_match_the_one_stream_run(world, monkeypatch
     p_one, l_one = run(True)
     assert torch.equal(l_multi, l_one) and torch.equal(p_multi, p_one)
     assert torch.isfinite(p_one).all() and (l_one[-1] < l_one[0]).item()
+
+
+def test_planned_no_grad_forward_with_two_chains_is_the_one_chain_forward(world):
+    """The planned forward under ``torch.no_grad()`` (predict / evaluators) with the encoder's tile-local launches split over
+    two streams: nothing but the plan's state holds the step tensors handed to the second stream once each Function has
+    returned (no autograd context), so the state must keep them until the join -- otherwise the caching allocator reuses
+    their blocks for the next main-stream launch while the part stream still reads or writes them.  Bit-identical logits
+    to the same forward with every launch on one stream, over several rounds with allocator churn in between."""
+    from bmp import packed
+    from bmp.dp import FlatAdam
+    w = world
+    opt = FlatAdam(w["model"], alpha=0.0)
+    pb = packed.pack_from_store(w["ms"], [w["i1"], w["i2"]], device=w["dev"])
+    assert pb.n_tiles >= 64
+    with torch.no_grad():
+        y0 = opt.functional_forward(pb).clone()
+    plan = opt.plan
+    assert plan is not None and plan.split is not None
+    outs = []
+    for rep in range(4):
+        with torch.no_grad():
+            y = opt.functional_forward(pb)
+            junk = [torch.full((pb.n_rows, 128), float(rep), device=w["dev"]) for _ in range(3)]     # takes freed blocks at once
+            outs.append(y.clone())
+            del junk
+    saved_split, saved_side = plan.split, plan.side
+    plan.split = plan.side = None
+    try:
+        with torch.no_grad():
+            y_one = opt.functional_forward(pb).clone()
+    finally:
+        plan.split, plan.side = saved_split, saved_side
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_one).all()
+    for y in [y0] + outs:
+        assert torch.equal(y, y_one)

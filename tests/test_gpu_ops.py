@@ -26,14 +26,9 @@ def dev():
 
 def close(got, ref, name="", tol=TOL, floor=1e-6):
     """max|got - ref| <= tol * max(max|ref|, floor).  ``floor`` is for quantities that are
-    analytically zero (their natural scale is not in the reference value)."""
-    got = got.detach().double().cpu()
-    ref = ref.detach().double().cpu()
-    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
-    scale = max(ref.abs().max().item(), floor)
-    err = (got - ref).abs().max().item()
-    assert err <= tol * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
-    return err / scale
+    analytically zero (their natural scale is not in the reference value).  Logs the achieved error (parity_util)."""
+    from parity_util import close as _c
+    return _c(got, ref, name, tol, floor)
 
 
 @pytest.fixture(scope="module")

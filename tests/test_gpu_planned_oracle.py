@@ -12,11 +12,7 @@ T = torch.from_numpy
 TOL = 1e-4
 
 
-def _close(got, want, name, tol=TOL):
-    got = got.detach().double().cpu(); want = want.detach().double()
-    scale = max(want.abs().max().item(), 1e-6)
-    err = (got - want).abs().max().item()
-    assert err <= tol * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+from parity_util import close as _close      # asserts AND logs the achieved relative error
 
 
 def _oracle_step(p, batch, encoder, n_layers, attn, alpha):

@@ -70,11 +70,7 @@ def test_link_predictors_match_oracle(kind, fp, C, hidden):
     y = lp(a, b)
     (y * cy.float().to(dev)).sum().backward()
 
-    def close(got, want, name, tol=1e-4):
-        got = got.detach().double().cpu(); want = want.detach()
-        scale = max(want.abs().max().item(), 1e-6)
-        err = (got - want).abs().max().item()
-        assert err <= tol * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+    from parity_util import close
     close(y, y_ref, "y")
     close(a.grad, x1.grad, "dx1")
     close(b.grad, x2.grad, "dx2")

@@ -109,3 +109,18 @@ def test_aromaticity_perception_of_kekule_input():
     assert _types("C1CCCCC1") == [SINGLE] * 6
     # aromatic input is left as written; mixing notations in one ring leaves the ring alone
     assert _types("c1ccccc1") == [AROMATIC] * 6
+
+
+def test_exocyclic_carbon_carbon_double_bonds_do_not_aromatise_a_ring():
+    """A double bond counts towards a ring's pi electrons only if the BOND lies in a ring: fulvene's exocyclic C=C and the
+    ylidene link of fulvalene leave their five-rings Kekule (hand-derived; RDKit reports no aromatic atoms for either)."""
+    _, b = bonds_of("C=C1C=CC=C1")                                      # fulvene
+    assert sum(t == AROMATIC for _, _, t in b) == 0 and sum(t == DOUBLE for _, _, t in b) == 3
+    _, b = bonds_of("C1=CC=CC1=C1C=CC=C1")                              # fulvalene: inter-ring C=C between two five-rings
+    assert sum(t == AROMATIC for _, _, t in b) == 0 and sum(t == DOUBLE for _, _, t in b) == 5
+    # ... while an exocyclic C=O still leaves its ring free to be aromatic (2-pyridone) and benzene rings next to an
+    # exocyclic C=C keep theirs (styrene)
+    _, b = bonds_of("O=C1C=CC=CN1")
+    assert sum(t == AROMATIC for _, _, t in b) == 6
+    _, b = bonds_of("C=CC1=CC=CC=C1")
+    assert sum(t == AROMATIC for _, _, t in b) == 6 and sum(t == DOUBLE for _, _, t in b) == 1
