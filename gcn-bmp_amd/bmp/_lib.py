@@ -86,9 +86,10 @@ SIGNATURES = {
     "bmp_gather_sum": (_I, [_P, _I, _P, _P, _I, _I, _P]),
     "bmp_adam_step": (_I, [_P, _P, _P, _P, _I, _F, _P, _F, _F, _F, _F, _F, _P]),
     "bmp_coattn_zcols": (_I, [_I, _I]),
-    "bmp_coattn_nie_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 17 + [_P]),
-    "bmp_coattn_nie_bwd_ws_floats": (_Z, [_I] * 6),
-    "bmp_coattn_nie_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I] + [_P] * 21 + [_Z, _P, _P, _P, _P]),
+    "bmp_coattn_nie_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 17 + [_P, _Z, _P]),
+    "bmp_coattn_big_ws_floats": (_Z, [_I] * 5),
+    "bmp_coattn_nie_bwd_ws_floats": (_Z, [_I] * 8),
+    "bmp_coattn_nie_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 21 + [_Z, _P, _P, _P, _P]),
 }
 
 _lib = None

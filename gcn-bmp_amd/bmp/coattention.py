@@ -34,21 +34,24 @@ class Bilinear(nn.Module):
 
 def _size_classes(nr1: np.ndarray, nr2: np.ndarray, device):
     """Pairs grouped by size class ceil(max(n1, n2) / 32): the pair kernels are launched once per
-    class with LDS sized for it (most drug pairs are <= 32 or <= 64 atoms)."""
-    cls = (np.maximum(nr1, nr2) + 31) // 32 - 1
+    class with LDS sized for it (most drug pairs are <= 32 or <= 64 atoms).  Class 4: a molecule of more than 128 rows
+    (more than one tile); those pairs run the same kernels out of global memory (bmp_coattn_nie_*: the `nbig` class).
+    Returns (order, counts[5], order_f, counts_f[5], np_big = largest row count among the class-4 pairs)."""
+    big = np.maximum(nr1, nr2)
+    cls = np.minimum((big + 31) // 32 - 1, 4)
     order = np.argsort(cls, kind="stable").astype(np.int32)
-    counts = np.bincount(cls, minlength=4)
-    if len(counts) > 4:
-        raise ValueError("a molecule has more than 128 rows")
-    # Forward: ONE launch sized by the largest class present, biggest pairs first.  Its LDS need is small (48 KB at 96
-    # rows: three workgroups per CU), and three launches of 35..550 workgroups each cost one workgroup's latency apiece.
-    # (The backward keeps the per-class launches: at 108 KB per 96-row pair one launch would run one pair per CU.)
-    top = int(np.nonzero(counts)[0].max())
-    counts_f = [0, 0, 0, 0]
-    counts_f[top] = int(len(cls))
+    counts = np.bincount(cls, minlength=5)
+    # Forward: the classes 0..3 as ONE launch sized by the largest of them, biggest pairs first.  Its LDS need is small
+    # (48 KB at 96 rows: three workgroups per CU), and three launches of 35..550 workgroups each cost one workgroup's
+    # latency apiece.  (The backward keeps the per-class launches: at 108 KB per 96-row pair one launch would run one pair
+    # per CU.)  The oversized pairs come first in the order and are a launch of their own.
+    counts_f = [0, 0, 0, 0, int(counts[4])]
+    if len(cls) > counts[4]:
+        counts_f[int(np.nonzero(counts[:4])[0].max())] = int(len(cls) - counts[4])
     order_f = np.argsort(-cls, kind="stable").astype(np.int32)
+    np_big = int(big[cls == 4].max()) if counts[4] else 0
     return (torch.from_numpy(order).to(device), [int(c) for c in counts],
-            torch.from_numpy(order_f).to(device), counts_f)
+            torch.from_numpy(order_f).to(device), counts_f, np_big)
 
 
 def _cbuf_floats(n1: np.ndarray, n2: np.ndarray) -> np.ndarray:
@@ -80,7 +83,7 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
                 r2=(pb1.mol_row0[B:] - T1 * R).contiguous(), n2=pb1.mol_nrows[B:].contiguous(),
                 coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
             (pb1._cache[key]["order"], pb1._cache[key]["counts"], pb1._cache[key]["order_f"],
-             pb1._cache[key]["counts_f"]) = _size_classes(nr[:B], nr[B:], pb1.device)
+             pb1._cache[key]["counts_f"], pb1._cache[key]["np_big"]) = _size_classes(nr[:B], nr[B:], pb1.device)
         m = pb1._cache[key]
         N1 = m["T1"] * R
         X1, X2 = at1.rows[:N1], at1.rows[N1:]
@@ -94,8 +97,17 @@ def pair_rows(at1: PackedAtoms, at2: PackedAtoms):
     coff = np.concatenate(([0], np.cumsum(_cbuf_floats(nr1, nr2))))
     m = dict(B=pb1.n_mols, T1=pb1.n_tiles, T2=pb2.n_tiles, r1=pb1.mol_row0, n1=pb1.mol_nrows, r2=pb2.mol_row0,
              n2=pb2.mol_nrows, coff=torch.from_numpy(coff[:-1].astype(np.int64)).to(pb1.device), ctotal=int(coff[-1]))
-    m["order"], m["counts"], m["order_f"], m["counts_f"] = _size_classes(nr1, nr2, pb1.device)
+    m["order"], m["counts"], m["order_f"], m["counts_f"], m["np_big"] = _size_classes(nr1, nr2, pb1.device)
     return at1.rows, at2.rows, pb1.row_w, pb2.row_w, m, False
+
+
+def _big_ws(meta, H, o, device):
+    """Workspace of the pair kernels' oversized class (pairs with a molecule of more than 128 rows): (tensor or None, floats)."""
+    nbig = meta["counts_f"][4]
+    if not nbig:
+        return None, 0
+    n = _lib.lib().bmp_coattn_big_ws_floats(meta["np_big"], H, o, nbig, 0)
+    return _ws(n, device), n
 
 
 class NieCoattnFn(Function):
@@ -116,11 +128,12 @@ class NieCoattnFn(Function):
         Cbuf = f(max(meta["ctotal"], 1))
         H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)      # written / read only at rows that belong to a pair
         out1, out2 = f(B, o), f(B, o)
+        wsb, nwsb = _big_ws(meta, H, o, dev)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
                                    ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order_f"]),
-                                   *meta["counts_f"], ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2), ptr(cbias), ptr(Q2),
-                                   ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(out1),
-                                   ptr(out2), stream()), "bmp_coattn_nie_fwd")
+                                   *meta["counts_f"], meta["np_big"], ptr(WbT), ptr(ZW1T), ptr(ZW2T), ptr(zb), ptr(wa1), ptr(wa2),
+                                   ptr(cbias), ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(out1),
+                                   ptr(out2), ptr(wsb), nwsb, stream()), "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, WbT, ZW1T, ZW2T, wa1, wa2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
         ctx.meta, ctx.dims = meta, (d, o, H, act, ZC, mode)
         return out1, out2
@@ -140,11 +153,11 @@ class NieCoattnFn(Function):
         dX1, dX2 = f(*X1.shape), f(*X2.shape)
         dWbT, dZW1T, dZW2T, dwa = f(d, d), f(d, ZC), f(d, ZC), f(2 * H + 1)
         dzb = f(2, ZC) if mode & 2 else f(ZC)
-        nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
+        nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B, meta["counts"][4], meta["np_big"])
         ws = _ws(nws, dev)
         check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1),
                                    ptr(meta["r1"]), ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]),
-                                   ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], ptr(Wb), ptr(ZW1), ptr(ZW2), ptr(wa1),
+                                   ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], meta["np_big"], ptr(Wb), ptr(ZW1), ptr(ZW2), ptr(wa1),
                                    ptr(wa2),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
@@ -177,11 +190,13 @@ class PNieFn(Function):
         Cbuf = f(max(meta["ctotal"], 1))
         H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)
         out1, out2 = f(B, o), f(B, o)
+        wsb, nwsb = _big_ws(meta, H, o, dev)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
                                    ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]), ptr(meta["coff"]), B, ptr(meta["order_f"]),
-                                   *meta["counts_f"], ptr(W["WbT"]), ptr(W["ZW1T"]), ptr(W["ZW2T"]), ptr(W["zb"]), ptr(W["wa1"]),
-                                   ptr(W["wa2"]), ptr(W["cbias"]), ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2),
-                                   ptr(al1), ptr(al2), ptr(out1), ptr(out2), stream()), "bmp_coattn_nie_fwd")
+                                   *meta["counts_f"], meta["np_big"], ptr(W["WbT"]), ptr(W["ZW1T"]), ptr(W["ZW2T"]), ptr(W["zb"]),
+                                   ptr(W["wa1"]), ptr(W["wa2"]), ptr(W["cbias"]), ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1),
+                                   ptr(H2), ptr(al1), ptr(al2), ptr(out1), ptr(out2), ptr(wsb), nwsb, stream()),
+              "bmp_coattn_nie_fwd")
         ctx.save_for_backward(X1, X2, w1, w2, Q2, Z1, Z2, Cbuf, H1, H2, al1, al2)
         ctx.meta, ctx.dims, ctx.W, ctx.G = meta, (d, o, H, act, ZC, mode), W, G
         flush_deferred(state)          # the readout the encoder held back: behind this call's launches in the queues
@@ -200,11 +215,11 @@ class PNieFn(Function):
             dX1, dX2 = dX[:X1.shape[0]], dX[X1.shape[0]:]
         else:
             dX1, dX2 = torch.empty_like(X1), torch.empty_like(X2)
-        nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B)
+        nws = L.bmp_coattn_nie_bwd_ws_floats(T1, T2, d, o, H, B, meta["counts"][4], meta["np_big"])
         ws = _ws(nws, X1.device)
         check(L.bmp_coattn_nie_bwd(ptr(dout1), ptr(dout2), ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1),
                                    ptr(meta["r1"]), ptr(meta["n1"]), ptr(w2), ptr(meta["r2"]), ptr(meta["n2"]),
-                                   ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], ptr(W["Wb"]), ptr(W["ZW1"]),
+                                   ptr(meta["coff"]), B, ptr(meta["order"]), *meta["counts"], meta["np_big"], ptr(W["Wb"]), ptr(W["ZW1"]),
                                    ptr(W["ZW2"]), ptr(W["wa1"]), ptr(W["wa2"]),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(G["dWbT"]), ptr(G["dZW1T"]), ptr(G["dZW2T"]), ptr(G["dzb"]), ptr(G["dwa"]),

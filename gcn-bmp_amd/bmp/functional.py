@@ -314,7 +314,7 @@ def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o, st=None, out=None):
     else:
         ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
         g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
-    if pb.row_mol is not None and L.bmp_readout_tile_supported(d, d0, o):
+    if pb.row_mol is not None and not pb.oversized and L.bmp_readout_tile_supported(d, d0, o):
         if WTp is None:
             WTp = pack_k4(WT)
         check(L.bmp_readout_tile_fwd(ptr(h), ptr(h0), pb.n_tiles, d, ptr(WTp), ptr(b), act_j, ptr(pb.row_w), ptr(pb.row_mol),
@@ -469,19 +469,50 @@ def _fwd_parts(state, pb, keep=()):
     if sp is None or T < 64:
         return ((0, T, stream()),)
     T0 = pb.side_tiles[1] if (len(pb.side_tiles) == 3 and 0 < pb.side_tiles[1] < T) else T // 2
-    sp.stream.wait_stream(torch.cuda.current_stream())
+    cur = torch.cuda.current_stream()
+    forked = state.get("split_forked", False)          # fork_parts: the chains were opened once for the whole encoder call
+    if not forked:
+        sp.stream.wait_stream(cur)
     state["split_open"] = True
     state.setdefault("split_keep", []).append(keep)
+    if sp.more:              # diagnostic: 2 + len(more) chains (BMP_FWD_CHAINS), each side's range cut into equal pieces
+        n = 2 + len(sp.more)
+        handles = [stream(), sp.handle] + sp.more_handles
+        if not forked:
+            for s_ in sp.more:
+                s_.wait_stream(cur)
+        cuts = [0] + [((T0 * 2 * k) // n if (2 * k) // n == 0 else T0 + ((T - T0) * (2 * k - n)) // n) for k in range(1, n)] + [T]
+        return tuple((cuts[k], cuts[k + 1] - cuts[k], handles[k]) for k in range(n) if cuts[k + 1] > cuts[k])
     return ((0, T0, stream()), (T0, T - T0, sp.handle))
+
+
+def fork_parts(state, pb) -> bool:
+    """Open the chains ONCE for a run of tile-local launches whose outputs the caller has already allocated (the planned
+    encoder allocates every step's outputs first): the part stream(s) pick up behind the current stream here, and the
+    launches that follow on either stream carry no further cross-stream wait until ``_join_parts`` -- each wait is a barrier
+    packet between two hardware queues (tens of microseconds) and, placed before every step, it ties chain B's step t to
+    chain A's step t-1 (rocprofv3 kernel trace).  Returns whether the chains are open."""
+    sp = state.get("split") if state is not None else None
+    if sp is None or pb.n_tiles < 64 or not _FORK_ONCE:
+        return False
+    cur = torch.cuda.current_stream()
+    sp.stream.wait_stream(cur)
+    for s_ in sp.more:
+        s_.wait_stream(cur)
+    state["split_forked"] = True
+    state["split_open"] = True
+    return True
 
 
 def _join_parts(state) -> None:
     if state is not None and state.get("split_open"):
         state["split"].join()
         state["split_open"] = False
+        state["split_forked"] = False
         state["split_keep"] = []
 
 
+_FORK_ONCE = os.environ.get("BMP_FWD_FORK_ONCE", "1") != "0"          # A/B switch of fork_parts
 _RO_DEFER = os.environ.get("BMP_READOUT_DEFER", "1") != "0"
 _RO_OFF_CHAIN = os.environ.get("BMP_READOUT_OFF_CHAIN", "1") != "0"        # A/B switch of PReadoutFn's off_chain form
 
@@ -541,18 +572,23 @@ class PEmbedFn(Function):
         return None, None, None, None, None
 
 
+def step_buffers(N: int, d: int, device):
+    """(m, rz, c, hout) of one fused propagation step."""
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+    return f(N, d), f(N, 2 * d), f(N, d), f(N, d)
+
+
 class PStepFn(Function):
     """GGNNStepFn on prepared weights.  W: WTp, bE, ATp, UcTp, b, Wnat_p, A_p, Uc_p; G: o1, o2, dUcT, cs of the
     step's weight group; ``state[gkey]`` says whether the group's buffers already hold a step of this backward."""
 
     @staticmethod
-    def forward(ctx, h, pb, W, G, state, gkey, first):
+    def forward(ctx, h, pb, W, G, state, gkey, first, bufs=None):
         L = _lib.lib()
         require_rows(h, "step: h")
         _check_pb(pb, h)
         N, d = h.shape
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
-        m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
+        m, rz, c, hout = bufs if bufs is not None else step_buffers(N, d, h.device)
         for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                       ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
@@ -583,7 +619,7 @@ class PStepFn(Function):
                                         ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
 
         _on_side(ctx.state, (h, m, rz, gda), wgrad)
-        return dh, None, None, None, None, None, None
+        return dh, None, None, None, None, None, None, None
 
 
 class PReadoutFn(Function):
@@ -742,11 +778,15 @@ def rel_layer_supported(d_in: int, d_out: int) -> bool:
     return bool(_lib.lib().bmp_relgcn_layer_supported(int(d_in), int(d_out)))
 
 
-def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None):
+def rel_buffers(N: int, d: int, device):
+    """(out, wdeg) of one fused RelGCN layer."""
+    return torch.empty(N, d, dtype=torch.float32, device=device), torch.empty(N, 4, dtype=torch.float32, device=device)
+
+
+def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None, bufs=None):
     L = _lib.lib()
     N, d = x.shape
-    out = torch.empty(N, d, dtype=torch.float32, device=x.device)
-    wdeg = torch.empty(N, 4, dtype=torch.float32, device=x.device)
+    out, wdeg = bufs if bufs is not None else rel_buffers(N, d, x.device)
     for t0, nt, st in _fwd_parts(state, pb, (x, out, wdeg)):
         check(L.bmp_relgcn_layer_fwd(ptr(x), t0, nt, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
                                      ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), st), "bmp_relgcn_layer_fwd")
@@ -802,10 +842,10 @@ class PRelLayerFn(Function):
     """RelLayerFn on prepared weights (bmp/plan.py).  W: WTp, bE, WsTp, bs, Wnat_p, Ws_p; G: o1 [d x 5d], dbE, cs [5d]."""
 
     @staticmethod
-    def forward(ctx, x, pb, W, G, state, gkey, act):
+    def forward(ctx, x, pb, W, G, state, gkey, act, bufs=None):
         require_rows(x, "relgcn layer: x")
         _check_pb(pb, x)
-        out, wdeg = _rel_fwd(x, pb, W["WTp"], W["bE"], W["WsTp"], W["bs"], act, state)
+        out, wdeg = _rel_fwd(x, pb, W["WTp"], W["bE"], W["WsTp"], W["bs"], act, state, bufs)
         ctx.save_for_backward(x, out, wdeg)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
         _register(state, gkey)
@@ -818,4 +858,4 @@ class PRelLayerFn(Function):
         first = _first_write(ctx.state, ctx.gkey)
         dx = _rel_bwd(dout.contiguous(), out, x, wdeg, ctx.pb, W["Wnat_p"], W["Ws_p"], ctx.act, G["o1"], G["dbE"], G["cs"],
                       0 if first else 1, ctx.state)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None

@@ -126,14 +126,19 @@ def packed_atoms_from_dense(x: torch.Tensor) -> PackedAtoms:
         raise ValueError("dense atom arrays must be float32 CUDA tensors of shape (mb, N, hidden_dim)")
     mb, N, d = x.shape
     R = _lib.lib().bmp_tile_rows()
-    if N < 1 or N > R:
-        raise ValueError(f"a molecule of {N} positions does not fit a tile of {R} rows")
+    if N < 1:
+        raise ValueError("dense atom arrays need at least one position per molecule")
     key = (mb, N, x.device)
     if key not in _DENSE_PB_CACHE:
-        per = R // N
-        n_tiles = (mb + per - 1) // per
         b = np.arange(mb)
-        row0 = (b // per) * R + (b % per) * N
+        if N <= R:
+            per = R // N
+            n_tiles = (mb + per - 1) // per
+            row0 = (b // per) * R + (b % per) * N
+        else:                                   # more positions than a tile has rows: whole consecutive tiles per molecule
+            per_mol = (N + R - 1) // R
+            n_tiles = mb * per_mol
+            row0 = b * per_mol * R
         idx = (row0[:, None] + np.arange(N)[None, :]).reshape(-1)
         n_rows = n_tiles * R
         row_w = np.zeros(n_rows, np.float32); row_w[idx] = 1.0
@@ -375,12 +380,16 @@ class GGNN(nn.Module):
             return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
                                        dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
                                        getattr(self, "_readout_off_chain", False))
+        # every step's outputs first, then the two chains of tiles are opened ONCE (Fn.fork_parts) and run to the join
+        # without another cross-stream wait
+        bufs = [Fn.step_buffers(h.shape[0], self.hidden_dim, h.device) for _ in range(self.n_layers)]
+        Fn.fork_parts(state, pb)
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
                      b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])
             g = f"g{li}_{mode}"
             Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
-            h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0)
+            h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0, bufs[step])
         Fn._join_parts(state)                 # the steps ran as two chains of tiles: whole arrays are read from here on
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
@@ -405,14 +414,15 @@ class GGNN(nn.Module):
         else:
             pb = as_packed(atom_array, adj, dev)
         fast = getattr(self, "_fast", None)
-        if fast is not None and not drop:
+        big = pb.oversized              # a molecule spans tiles (train_ddi_modify.py:256 sets no size limit): row-wise operators
+        if fast is not None and not drop and not big:
             return self._forward_fast(pb, fast, h_in)
         if h_in is None:
             pb.check_atom_ids(self.embed.W.shape[0])
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id) if h_in is None else h_in      # :603
         h0 = h                                                          # :612
         later = None
-        fused = self.fused and Fn.step_supported(self.hidden_dim) and not drop
+        fused = self.fused and Fn.step_supported(self.hidden_dim) and not drop and not big
         state, state_w = None, None           # dropout: the GRU's own (un-dropped) state and its unfolded weights
         masks = getattr(self, "_dropout_masks", None)      # tests inject the masks (one (n_rows, d) tensor per step)
         g_list = []

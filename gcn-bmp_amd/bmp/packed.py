@@ -85,24 +85,36 @@ class MolStore:
 
 def _bin_pack(sizes: np.ndarray, R: int) -> Tuple[np.ndarray, np.ndarray, int]:
     """First-fit-decreasing of item sizes into bins of capacity R.
-    Returns (bin index, offset inside bin) per item and the bin count."""
-    if len(sizes) and int(sizes.max()) > R:
-        raise ValueError(f"molecule with {int(sizes.max())} rows does not fit a tile of R={R}")
+    Returns (bin index, offset inside bin) per item and the bin count.
+
+    An item LARGER than a bin (a molecule of more than R - 1 atoms: the reference's preprocessor has no size limit,
+    train_ddi_modify.py:256) takes ceil(size / R) whole consecutive bins of its own, from a bin boundary; such items come
+    first, in the stable decreasing-size order, and what is left of their last bin stays empty (dead rows).  The batch
+    then holds rows whose neighbours live in another tile, and the encoders take the row-wise operators for it (bmp/ggnn.py)."""
     order = np.argsort(-sizes, kind="stable")
     caps = np.full(len(sizes) + 1, R, dtype=np.int64)
     nb = 0
     bins = np.zeros(len(sizes), dtype=np.int64)
     offs = np.zeros(len(sizes), dtype=np.int64)
+    first = 0                      # bins [0, first) belong to the oversized items
     for it in order:
         s = int(sizes[it])
+        if s <= R:
+            break
+        bins[it] = first
+        first += (s + R - 1) // R
+    for it in order:
+        s = int(sizes[it])
+        if s > R:
+            continue
         fit = caps[:nb] >= s
         b = int(np.argmax(fit)) if nb and fit.any() else nb
         if b == nb:
             nb += 1
-        bins[it] = b
+        bins[it] = first + b
         offs[it] = R - caps[b]
         caps[b] -= s
-    return bins, offs, nb
+    return bins, offs, first + nb
 
 
 @dataclass
@@ -140,6 +152,13 @@ class PackedMolBatch:
     @property
     def device(self) -> torch.device:
         return self.atom_id.device
+
+    @property
+    def oversized(self) -> bool:
+        """A molecule of this batch spans more than one tile (more than R - 1 atoms): neighbour gathers are not tile-local,
+        the encoders take the row-wise operators (gather over global rows, row GEMMs, per-molecule segment sums) and the
+        co-attention the global-memory class of its pair kernels."""
+        return self.max_rows_per_mol > self.R
 
     def check_atom_ids(self, n_atom_types: int) -> None:
         """EmbedID's type check (chainer rejects ids outside the table; models/ggnn.py:85,603): raise before any kernel
@@ -545,10 +564,10 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
         dstore.st_nrows, dstore.st_nedges, sides, R, pad_to, tab=st_np[:6 * I])
     counts, ctotal = None, 0
     if paired:
-        cnt = np.zeros(4, dtype=np.int32); ct = np.zeros(1, dtype=np.int64)
+        cnt = np.zeros(6, dtype=np.int32); ct = np.zeros(1, dtype=np.int64)
         check(L.bmp_collate_pair_meta(_i32p(st_np), I, B, side_tiles[1], R, _i32p(st_np[n_tab:]), _i32p(cnt), _i32p(ct)),
               "bmp_collate_pair_meta")
-        counts, ctotal = [int(c) for c in cnt], int(ct[0])
+        counts, ctotal, np_big = [int(c) for c in cnt[:5]], int(ct[0]), int(cnt[5])
     if lab is not None:
         st_np[n_tab + n_meta:n_tab + n_meta + n_lab] = lab
     dstore.plan_seconds += _time.perf_counter() - t_plan          # the host's share of the collate (size arithmetic)
@@ -584,12 +603,14 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
         mol_nrows_host=nrows_host, row_mol=row_mol, atom_id_range=dstore.atom_id_range)
     if paired:
         m = up[n_tab:n_tab + n_meta]
-        top = max(k for k in range(4) if counts[k])
-        counts_f = [0, 0, 0, 0]; counts_f[top] = B
+        # forward: the pairs of the classes 0..3 as ONE launch sized by the largest of them, the oversized pairs (class 4) apart
+        counts_f = [0, 0, 0, 0, counts[4]]
+        if B > counts[4]:
+            counts_f[max(k for k in range(4) if counts[k])] = B - counts[4]
         pb._cache["pair_meta"] = dict(
             B=B, T1=side_tiles[1], T2=side_tiles[2] - side_tiles[1], coff=m[:2 * B].view(torch.int64), r1=m[2 * B:3 * B],
             n1=m[3 * B:4 * B], r2=m[4 * B:5 * B], n2=m[5 * B:6 * B], order=m[6 * B:7 * B], order_f=m[7 * B:8 * B],
-            counts=counts, counts_f=counts_f, ctotal=ctotal)
+            counts=counts, counts_f=counts_f, ctotal=ctotal, np_big=np_big)
     if lab is None:
         return pb
     return pb, up[n_tab + n_meta:].view(np.asarray(labels).shape if np.asarray(labels).ndim > 1 else (-1,))

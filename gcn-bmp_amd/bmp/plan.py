@@ -112,15 +112,21 @@ class SideStream:
 
 class PartStream:
     """An ordinary stream for the second half of the planned encoder's tile-local forward launches
-    (functional._fwd_parts)."""
+    (functional._fwd_parts).  ``extra`` more streams (BMP_FWD_CHAINS - 2, default none): the four-chain diagnostic form of
+    DESIGN.md 3a' (the stream-count cliff); the product runs two chains."""
 
-    def __init__(self, device):
+    def __init__(self, device, extra: int = 0):
         import ctypes
         self.stream = torch.cuda.Stream(device=torch.device(device))
         self.handle = ctypes.c_void_p(self.stream.cuda_stream)
+        self.more = [torch.cuda.Stream(device=torch.device(device)) for _ in range(max(int(extra), 0))]
+        self.more_handles = [ctypes.c_void_p(s.cuda_stream) for s in self.more]
 
     def join(self) -> None:
-        torch.cuda.current_stream().wait_stream(self.stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.stream)
+        for s in self.more:
+            cur.wait_stream(s)
 
 
 class LayoutPlan:
@@ -167,8 +173,8 @@ class LayoutPlan:
         one = os.environ.get("BMP_ONE_STREAM") == "1"        # profiling: every launch in line on the caller's stream
         self.side = SideStream(device) if (torch.device(device).type == "cuda" and not one
                                            and os.environ.get("BMP_WGRAD_STREAM", "1") != "0") else None
-        self.split = PartStream(device) if (torch.device(device).type == "cuda" and not one
-                                            and os.environ.get("BMP_FWD_SPLIT", "1") != "0") else None
+        self.split = PartStream(device, int(os.environ.get("BMP_FWD_CHAINS", "2")) - 2) if (
+            torch.device(device).type == "cuda" and not one and os.environ.get("BMP_FWD_SPLIT", "1") != "0") else None
         self.state: Dict[str, dict] = {}
         self._views()
 

@@ -60,7 +60,7 @@ class RelGCNUpdate(nn.Module):
         """hs + sum_e adj_e (W_e h + b_e) (relgcn_update.py:24-44); ``act`` lets the caller fuse the
         tanh of models/relgcn.py:71 into the same kernel."""
         WT, bE = message_kernel_weights(self.graph_linear_edge)
-        if h.is_cuda and Fn.rel_layer_supported(self.in_channels, self.out_channels):
+        if h.is_cuda and not pb.oversized and Fn.rel_layer_supported(self.in_channels, self.out_channels):
             return Fn.RelLayerFn.apply(h, WT, bE, self.graph_linear_self.W.t(), self.graph_linear_self.b, pb, Fn.ACT[act])
         return Fn.MsgFn.apply(h, WT, bE, self.graph_linear_self.W.t(), self.graph_linear_self.b, pb, Fn.ACT[act])
 
@@ -201,11 +201,16 @@ class RelGCN(nn.Module):
         pb.check_atom_ids(P["embed.W"].shape[0])
         x = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
         pbs = rescale_adj(pb) if self.scale_adj else pb
+        all_fused = all(self._fused(l) for l in range(len(self.rgcn_convs)))
+        bufs = None
+        if all_fused:         # every layer's outputs first, then the chains of tiles opened once (Fn.fork_parts)
+            bufs = [Fn.rel_buffers(x.shape[0], self.rgcn_convs[l].out_channels, x.device) for l in range(len(self.rgcn_convs))]
+            Fn.fork_parts(state, pb)
         for l in range(len(self.rgcn_convs)):
             if self._fused(l):
                 W = {k: P[f"c{l}.{k}"] for k in ("WTp", "bE", "WsTp", "bs", "Wnat_p", "Ws_p")}
                 Gl = {k: G[f"c{l}.{k}"] for k in ("o1", "dbE", "cs")}
-                x = Fn.PRelLayerFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
+                x = Fn.PRelLayerFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"], None if bufs is None else bufs[l])
                 continue
             W = {k: P[f"c{l}.{k}"] for k in ("WT", "bE", "WsT", "bs", "Wnat", "Ws")}
             Gl = {k: G[f"c{l}.{k}"] for k in ("dWT", "dbE", "dWsT", "dbs")}
@@ -235,7 +240,7 @@ class RelGCN(nn.Module):
         else:
             pb = as_packed(h, adj, self.embed.W.device)
             fast = getattr(self, "_fast", None)
-            if fast is not None:
+            if fast is not None and not pb.oversized:         # (a molecule spanning tiles: row-wise operators below)
                 return self._forward_fast(pb, fast)
             pb.check_atom_ids(self.embed.W.shape[0])
             x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)

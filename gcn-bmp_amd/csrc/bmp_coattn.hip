@@ -40,6 +40,9 @@ struct CoArgs {
     float* dQ2; float* dX1;                    // [N2 x d], [N1 x d]
     float* dZ1; float* dZ2;                    // [N x ZC]
     float* dpart;                              // [B x (2H + 1)]: dwa1 | dwa2 | dc
+    // the oversized class (BIG kernels: a molecule of more than CO_MAXN rows): the arrays the other classes keep in LDS
+    // live in a global workspace, one slice of big_stride floats per workgroup
+    float* big_ws; long long big_stride;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -70,7 +73,7 @@ struct CoLds {
     float* Up; float* dPp; float* cmb;   // [256], [256 x H], [np] per-thread partial sums / combined row sums (backward)
 };
 
-__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd, int o = 0, int nt = 256) {
+__device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, bool bwd, int o = 0, int nt = 256, bool big = false) {
     CoLds L;
     float* p = base;
     L.Cs = p; p += (size_t)np * ldc;
@@ -92,14 +95,21 @@ __device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, b
     L.do2 = p; if (bwd) p += o;
     L.cmb = p; if (bwd) p += np;
     // np == 128: SUB = 2, and the slots alias arrays that are dead by then (dots1|dots2 = 256, H1s|H2s = 256 x H)
-    if (np >= 128) { L.Up = L.dots1; L.dPp = L.H1s; }
+    if (big) { L.Up = p; if (bwd) p += np; L.dPp = p; if (bwd) p += np * H; }        // one slot per row (no row x chunk split)
+    else if (np >= 128) { L.Up = L.dots1; L.dPp = L.H1s; }
     else { L.Up = p; if (bwd) p += nt; L.dPp = p; if (bwd) p += nt * H; }
     return L;
 }
 
-static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0, int nt = 256) {
+static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0, int nt = 256, bool big = false) {
     return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 6 : 2) + 11 * (size_t)np + (bwd ? 2 * (size_t)o + np : 0) +
-           ((bwd && np < 128) ? nt + nt * (size_t)H : 0) + 8;
+           (big ? (bwd ? np + np * (size_t)H : 0) : ((bwd && np < 128) ? nt + nt * (size_t)H : 0)) + 8;
+}
+// the oversized class: rows rounded up to 32, the forward's pooled-output scratch (2 * NT floats) fits in the C image
+static int co_big_np(int np_big) { return (np_big + 31) & ~31; }
+static size_t co_big_stride(int np_big, int H, bool bwd, int o) {
+    const int np = co_big_np(np_big);
+    return (co_lds_floats(np, np + 1, H, bwd, o, 512, true) + 15) & ~(size_t)15;
 }
 
 // column / row softmax statistics of C with multiplicities:
@@ -167,6 +177,27 @@ __device__ __forceinline__ void co_stats_split(const CoLds& L, int n1, int n2, i
     }
 }
 
+// one thread per atom, atoms tid, tid + nt, ... (the oversized class)
+__device__ __forceinline__ void co_stats_split_big(const CoLds& L, int n1, int n2, int ldc, int nt) {
+    for (int a = threadIdx.x; a < n1 + n2; a += nt) {
+        if (a < n1) {
+            const int j = a;
+            float mx = -INFINITY;
+            for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
+            float s = 0.f;
+            for (int i = 0; i < n2; ++i) if (L.w2s[i] > 0.f) s += L.w2s[i] * bmp_exp(L.Cs[i * ldc + j] - mx);
+            L.cmax[j] = mx; L.invD2[j] = 1.f / s;
+        } else {
+            const int i = a - n1;
+            float mx = -INFINITY;
+            for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) mx = fmaxf(mx, L.Cs[i * ldc + j]);
+            float s = 0.f;
+            for (int j = 0; j < n1; ++j) if (L.w1s[j] > 0.f) s += L.w1s[j] * bmp_exp(L.Cs[i * ldc + j] - mx);
+            L.rmax[i] = mx; L.invD1[i] = 1.f / s;
+        }
+    }
+}
+
 // L2[i,j] (softmax over i) and L1[j,i] (softmax over j); zero-weight rows get weight 0 in every sum,
 // so their (possibly huge) exponent is never used.
 __device__ __forceinline__ float co_L2(const CoLds& L, int i, int j, int ldc) {
@@ -176,7 +207,10 @@ __device__ __forceinline__ float co_L1(const CoLds& L, int i, int j, int ldc) {
     return L.w1s[j] > 0.f ? bmp_exp(L.Cs[i * ldc + j] - L.rmax[i]) * L.invD1[i] : 0.f;
 }
 
-template <int HT, int NT>
+// BIG: the class of pairs with a molecule of more than CO_MAXN rows (more than one tile; the reference's preprocessor has
+// no size limit, train_ddi_modify.py:256).  Same program; the arrays the other classes keep in LDS live in the
+// workgroup's slice of a global workspace (a.big_ws), and every "one thread per atom" phase is a strided loop.
+template <int HT, int NT, bool BIG = false>
 __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     constexpr int NW = NT / 64;
     constexpr int HN = HT > 0 ? HT : CO_MAXH;       // head count known at compile time (8, 4) or runtime (<16)
@@ -187,16 +221,22 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     const int r1 = a.r1[b], n1 = a.n1[b], r2 = a.r2[b], n2 = a.n2[b];
     const int d = a.d, o = a.o, H = HT > 0 ? HT : a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
-    const CoLds L = co_carve(lds_raw, a.np, ldc, H, false);
+    const CoLds L = BIG ? co_carve(a.big_ws + (size_t)blockIdx.x * a.big_stride, a.np, ldc, H, false, 0, NT, true)
+                        : co_carve(lds_raw, a.np, ldc, H, false);
     const float cb = a.cbias[0];
 
     for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
+    if constexpr (BIG) {
+        for (int j = tid; j < n1; j += NT) L.w1s[j] = a.w1[r1 + j];
+        for (int i = tid; i < n2; i += NT) { L.w2s[i] = a.w2[r2 + i]; L.v2s[i] = a.Z2[(size_t)(r2 + i) * ZC + o + H]; }
+    } else {
     if (tid < n1) L.w1s[tid] = a.w1[r1 + tid];
     if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
         const int i = tid - CO_MAXN;
         L.w2s[i] = a.w2[r2 + i];
         L.v2s[i] = a.Z2[(size_t)(r2 + i) * ZC + o + H];
+    }
     }
     __syncthreads();
 
@@ -234,35 +274,44 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     if (a.mode == 1) {
         // PoolingFineCoattention (PoolingFineCoattention.py:40-51): the atom scores are the means of the energy
         // over the OTHER side's padded positions: e1[j] = sum_i w2_i C[i,j] / A2, e2[i] = sum_j w1_j C[i,j] / A1
-        if (tid < CO_MAXN) {
-            const int j = tid;
+        for (int t_ = tid; t_ < (BIG ? n1 + n2 : NT); t_ += NT) {
+        const bool s1 = BIG ? t_ < n1 : t_ < CO_MAXN;
+        if (s1) {
+            const int j = t_;
             if (j < n1) {
                 float s = 0.f, A2 = 0.f;
                 for (int i = 0; i < n2; ++i) { s += L.w2s[i] * L.Cs[i * ldc + j]; A2 += L.w2s[i]; }
                 L.s1[j] = s / A2;
             }
         } else {
-            const int i = tid - CO_MAXN;
+            const int i = t_ - (BIG ? n1 : CO_MAXN);
             if (i < n2) {
                 float s = 0.f, A1 = 0.f;
                 for (int j = 0; j < n1; ++j) { s += L.w1s[j] * L.Cs[i * ldc + j]; A1 += L.w1s[j]; }
                 L.s2[i] = s / A1;
             }
         }
+        }
     } else {
-    const int Q = co_split(n1, n2, NT);
-    co_stats_split(L, n1, n2, ldc, Q);
+    const int Q = BIG ? 1 : co_split(n1, n2, NT);
+    if constexpr (BIG) co_stats_split_big(L, n1, n2, ldc, NT);
+    else co_stats_split(L, n1, n2, ldc, Q);
     __syncthreads();
     {   // the backward reloads these instead of walking C again (17 % of its time): kept behind the pair's C block
         float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
+        if constexpr (BIG) {
+            for (int j = tid; j < n1; j += NT) { st[j] = L.cmax[j]; st[n1 + j] = L.invD2[j]; }
+            for (int i = tid; i < n2; i += NT) { st[2 * n1 + i] = L.rmax[i]; st[2 * n1 + n2 + i] = L.invD1[i]; }
+        } else {
         if (tid < CO_MAXN) { if (tid < n1) { st[tid] = L.cmax[tid]; st[n1 + tid] = L.invD2[tid]; } }
         else if (tid < 2 * CO_MAXN) { const int i = tid - CO_MAXN; if (i < n2) { st[2 * n1 + i] = L.rmax[i]; st[2 * n1 + n2 + i] = L.invD1[i]; } }
+        }
     }
     __syncthreads();
 
     // ---- head projections: H1 = tanh(P1 + L1 . P2), H2 = tanh(P2 + L2 . P1)  (:352-362), Q lanes per atom ----
-    {
-        const int a_ = tid / Q, q = tid % Q;
+    for (int a_ = tid / Q; a_ < (BIG ? n1 + n2 : tid / Q + 1); a_ += NT) {      // BIG: Q = 1, atoms tid, tid + NT, ...
+        const int q = tid % Q;
         const bool side1 = a_ < n1, valid = a_ < n1 + n2;
         const int me = side1 ? a_ : a_ - n1;
         const int no = side1 ? n2 : n1;
@@ -356,7 +405,7 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
 // NT threads per pair: the phases are strided loops, (row, chunk) decompositions and MFMA blocks per wave, so a bigger
 // pair takes more waves (a launch of a size class lasts about one workgroup's latency; a 96-row pair took 120 us with
 // 256 threads).  The per-row phases (one thread per atom of either side) use the first 2 * CO_MAXN threads.
-template <int HT, int NT>
+template <int HT, int NT, bool BIG = false>
 __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     constexpr int NW = NT / 64;
     constexpr int HN = HT > 0 ? HT : CO_MAXH;
@@ -368,22 +417,33 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     const int d = a.d, o = a.o, H = HT > 0 ? HT : a.H, ZC = a.ZC, ldc = a.ldc;
     const int nb1 = (n1 + 31) >> 5, nb2 = (n2 + 31) >> 5;
     const int n1p = nb1 * 32, n2p = nb2 * 32;
-    const CoLds L = co_carve(lds_raw, a.np, ldc, H, true, o, NT);
+    const CoLds L = BIG ? co_carve(a.big_ws + (size_t)blockIdx.x * a.big_stride, a.np, ldc, H, true, o, NT, true)
+                        : co_carve(lds_raw, a.np, ldc, H, true, o, NT);
     // ---- load the pair's saved state ----
     {   // column / row softmax statistics of C: saved by the forward behind the pair's C block
         const float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
+        if constexpr (BIG) {
+            for (int j = tid; j < n1; j += NT) { L.cmax[j] = st[j]; L.invD2[j] = st[n1 + j]; }
+            for (int i = tid; i < n2; i += NT) { L.rmax[i] = st[2 * n1 + i]; L.invD1[i] = st[2 * n1 + n2 + i]; }
+        } else {
         if (tid < CO_MAXN) { if (tid < n1) { L.cmax[tid] = st[tid]; L.invD2[tid] = st[n1 + tid]; } }
         else if (tid < 2 * CO_MAXN) { const int i = tid - CO_MAXN; if (i < n2) { L.rmax[i] = st[2 * n1 + i]; L.invD1[i] = st[2 * n1 + n2 + i]; } }
+        }
     }
     for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n1 * H; idx += NT) L.H1s[idx] = a.H1[(size_t)r1 * H + idx];
     for (int idx = tid; idx < n2 * H; idx += NT) L.H2s[idx] = a.H2[(size_t)r2 * H + idx];
     for (int c = tid; c < o; c += NT) { L.do1[c] = a.dout1[(size_t)b * o + c]; L.do2[c] = a.dout2[(size_t)b * o + c]; }
+    if constexpr (BIG) {
+        for (int j = tid; j < n1; j += NT) { L.w1s[j] = a.w1[r1 + j]; L.s1[j] = a.al1[r1 + j]; }
+        for (int i = tid; i < n2; i += NT) { L.w2s[i] = a.w2[r2 + i]; L.s2[i] = a.al2[r2 + i]; }
+    } else {
     if (tid < n1) { L.w1s[tid] = a.w1[r1 + tid]; L.s1[tid] = a.al1[r1 + tid]; }
     if (tid >= CO_MAXN && tid - CO_MAXN < n2) {
         const int i = tid - CO_MAXN;
         L.w2s[i] = a.w2[r2 + i]; L.s2[i] = a.al2[r2 + i];
+    }
     }
     {
         const float* cg = a.Cbuf + a.coff[b];
@@ -502,9 +562,11 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     //      U1_i = sum_j L1*w2_i*g1 ;  dP2[i,:] = dH2[i,:] + w2_i * sum_j L1 * dH1[j,:]      (and symmetrically L2).
     //      Partial sums go to per-thread LDS slots and are combined in a fixed order (reproducible). ----
     const int np_ = a.np;
-    const int SUB = NT / np_;
-    const int prow = tid % np_, pq = tid / np_;
-    {   // L1 path, pass 1
+    const int SUB = BIG ? 1 : NT / np_;                  // BIG: one slot per row, rows tid, tid + NT, ...
+    const int pq = BIG ? 0 : tid / np_;
+    const int prow0 = BIG ? tid : tid % np_, prow_step = BIG ? NT : np_ * (SUB > 0 ? SUB : 1) + NT;      // non-BIG: one pass
+#define CO_SLOT(row) (BIG ? (row) : tid)
+    for (int prow = prow0; prow < (BIG ? n2 : np_); prow += prow_step) {   // L1 path, pass 1
         float U = 0.f, dp[HN];
 #pragma unroll
         for (int h = 0; h < HN; ++h) dp[h] = 0.f;
@@ -527,15 +589,15 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
                 U += l1 * (w2i * g);
             }
         }
-        L.Up[tid] = U;
+        L.Up[CO_SLOT(prow)] = U;
 #pragma unroll
-        for (int h = 0; h < HN; ++h) if (h < H) L.dPp[tid * H + h] = dp[h];
+        for (int h = 0; h < HN; ++h) if (h < H) L.dPp[CO_SLOT(prow) * H + h] = dp[h];
     }
     __syncthreads();
-    if (tid < n2) {          // U1_i in a fixed order
+    for (int i = tid; i < n2; i += NT) {          // U1_i in a fixed order
         float u = 0.f;
-        for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + tid];
-        L.cmb[tid] = u;
+        for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + i];
+        L.cmb[i] = u;
     }
     for (int idx = tid; idx < n2 * H; idx += NT) {       // dP2 -> dZ2
         const int i = idx / H, h = idx % H;
@@ -544,6 +606,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         a.dZ2[(size_t)(r2 + i) * ZC + o + h] = v;
     }
     __syncthreads();
+    for (int prow = prow0; prow < (BIG ? n2 : np_); prow += prow_step)
     if (pq < SUB && prow < n2) {   // L1 path, pass 2: dS <- dC1
         const int i = prow;
         const int chunk = (n1 + SUB - 1) / SUB, j0 = pq * chunk, j1 = (j0 + chunk) < n1 ? (j0 + chunk) : n1;
@@ -560,7 +623,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         }
     }
     __syncthreads();
-    {   // L2 path, pass 1
+    for (int prow = prow0; prow < (BIG ? n1 : np_); prow += prow_step) {   // L2 path, pass 1
         float U = 0.f, dp[HN];
 #pragma unroll
         for (int h = 0; h < HN; ++h) dp[h] = 0.f;
@@ -583,15 +646,15 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
                 U += l2 * (w1j * g);
             }
         }
-        L.Up[tid] = U;
+        L.Up[CO_SLOT(prow)] = U;
 #pragma unroll
-        for (int h = 0; h < HN; ++h) if (h < H) L.dPp[tid * H + h] = dp[h];
+        for (int h = 0; h < HN; ++h) if (h < H) L.dPp[CO_SLOT(prow) * H + h] = dp[h];
     }
     __syncthreads();
-    if (tid < n1) {
+    for (int j = tid; j < n1; j += NT) {
         float u = 0.f;
-        for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + tid];
-        L.cmb[tid] = u;
+        for (int q = 0; q < SUB; ++q) u += L.Up[q * np_ + j];
+        L.cmb[j] = u;
     }
     for (int idx = tid; idx < n1 * H; idx += NT) {       // dP1 -> dZ1
         const int j = idx / H, h = idx % H;
@@ -600,6 +663,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         a.dZ1[(size_t)(r1 + j) * ZC + o + h] = v;
     }
     __syncthreads();
+    for (int prow = prow0; prow < (BIG ? n1 : np_); prow += prow_step)
     if (pq < SUB && prow < n1) {   // L2 path, pass 2: dS <- (dC1 + dC2) * act'(C)
         const int j = prow;
         const int chunk = (n2 + SUB - 1) / SUB, i0 = pq * chunk, i1 = (i0 + chunk) < n2 ? (i0 + chunk) : n2;
@@ -619,6 +683,28 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     }   // mode
     __syncthreads();
     // dv1[j] = sum_i dS[i,j] ; dv2[i] = sum_j dS[i,j] ; dc = sum_i dv2[i]
+    if constexpr (BIG) {
+        for (int j = tid; j < n1; j += NT) {
+            float dv1 = 0.f;
+            for (int i = 0; i < n2; ++i) dv1 += L.dSs[i * ldc + j];
+            a.dZ1[(size_t)(r1 + j) * ZC + o + H] = dv1;
+        }
+        float mine = 0.f;
+        for (int i = tid; i < n2; i += NT) {
+            float dv2 = 0.f;
+            for (int j = 0; j < n1; ++j) dv2 += L.dSs[i * ldc + j];
+            a.dZ2[(size_t)(r2 + i) * ZC + o + H] = dv2;
+            mine += dv2;
+        }
+        const float tot = wave_sum(mine);
+        if (lane == 0) L.dots1[wave] = tot;          // dots1 is dead by now; np >= 160 > NW
+        __syncthreads();
+        if (tid == 0) {
+            float dc = 0.f;
+            for (int q = 0; q < NW; ++q) dc += L.dots1[q];
+            a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = dc;
+        }
+    } else {
     if (tid < CO_MAXN) {
         const int j = tid;
         if (j < n1) {
@@ -638,6 +724,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     }
     __syncthreads();
     if (tid == 0) a.dpart[(size_t)b * (2 * H + 1) + 2 * H] = L.dots1[0] + L.dots1[1];
+    }
 
     // ---- energy backward on the matrix cores: dQ2 = dS . X1 ; dX1 = dS^T . Q2 ----
     for (int blk = wave; blk < (nb2 + nb1) * ncb; blk += NW) {
@@ -707,6 +794,13 @@ static int co_set_lds(const void* fn, size_t bytes) {
 // ZC = o + H + 1 rounded up to a multiple of 8: J (o) | P (H) | v | pad
 extern "C" int bmp_coattn_zcols(int o, int H) { return (o + H + 1 + 7) & ~7; }
 
+// Workspace (floats) of the oversized class of the pair kernels: nbig pairs whose largest molecule has np_big rows
+// (> 128); backward != 0: the backward's share (part of bmp_coattn_nie_bwd_ws_floats).  0 without such pairs.
+extern "C" size_t bmp_coattn_big_ws_floats(int np_big, int H, int o, int nbig, int backward) {
+    if (nbig <= 0 || np_big <= 0) return 0;
+    return (size_t)nbig * co_big_stride(np_big, H, backward != 0, o);
+}
+
 // Forward.  WbT [d x d] = W (bilinear form, [p][q]) so that Q2 = X2 . W^T uses it K-major as [q][p]:
 // pass WbT[q*d + p] = W[p][q].  ZW1T/ZW2T [d x ZC] K-major columns [Wj^T | Wl_k^T | V_k | 0]; zb [ZC] = [bj | 0].
 // mode bit 1 (value 2): one bias row per side, zb / dzb are [2 x ZC] (the Deep* variants, whose folded projections differ by side).
@@ -731,12 +825,14 @@ static int co_beside_classes(const int* cnt, hipStream_t st, hipStream_t st_b) {
 extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act, int mode,
                                   const float* w1, const int* r1, const int* n1, const float* w2, const int* r2,
                                   const int* n2, const long long* coff, int B, const int* order, int n32, int n64, int n96,
-                                  int n128, const float* WbT,
+                                  int n128, int nbig, int np_big, const float* WbT,
                                   const float* ZW1T, const float* ZW2T, const float* zb, const float* wa1,
                                   const float* wa2, const float* cbias, float* Q2, float* Z1, float* Z2, float* Cbuf,
-                                  float* H1, float* H2, float* al1, float* al2, float* out1, float* out2, hipStream_t st) {
+                                  float* H1, float* H2, float* al1, float* al2, float* out1, float* out2, float* ws_big,
+                                  size_t ws_big_floats, hipStream_t st) {
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
-    BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && n32 + n64 + n96 + n128 == B);
+    BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && nbig >= 0 && n32 + n64 + n96 + n128 + nbig == B);
+    BMP_REQUIRE(nbig == 0 || (np_big > CO_MAXN && ws_big && ws_big_floats >= bmp_coattn_big_ws_floats(np_big, H, o, nbig, 0)));
     const int ZC = bmp_coattn_zcols(o, H);
     int rc;
     {   // Q2 = X2 . WbT ; Z1 = X1 . ZW1T + zb ; Z2 = X2 . ZW2T + zb : three projections, one launch
@@ -761,9 +857,20 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     // one launch per size class: LDS (and so the workgroups per CU) follows the pairs' actual sizes.  (The callers hand
     // the forward ONE class sized by the largest pair: its own class for a handful of big pairs, beside the others on a
     // second stream as the backward does below, measured 0.5 % slower on the C2 / C3 steps.)
-    const int cnt[4] = {n32, n64, n96, n128};
+    // (`order` lists the classes in DESCENDING size for this entry point: the oversized pairs first)
     int off = 0;
-    for (int c = 0; c < 4; ++c) {
+    if (nbig > 0) {       // the oversized class: same program out of a global workspace (rare: a handful of pairs per batch)
+        a.np = co_big_np(np_big); a.ldc = a.np + 1; a.order_off = 0;
+        a.big_ws = ws_big; a.big_stride = (long long)co_big_stride(np_big, H, false, o);
+        BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st, BMP_KID_COATTN_FWD);
+        if (H == 8) hipLaunchKernelGGL((k_coattn_fwd<8, CO_NT_FWD, true>), dim3(nbig), dim3(CO_NT_FWD), 0, st, a);
+        else if (H == 4) hipLaunchKernelGGL((k_coattn_fwd<4, CO_NT_FWD, true>), dim3(nbig), dim3(CO_NT_FWD), 0, st, a);
+        else hipLaunchKernelGGL((k_coattn_fwd<0, CO_NT_FWD, true>), dim3(nbig), dim3(CO_NT_FWD), 0, st, a);
+        BMP_LAUNCH_CHECK();
+        off = nbig;
+    }
+    const int cnt[4] = {n32, n64, n96, n128};
+    for (int c = 3; c >= 0; --c) {
         if (cnt[c] == 0) continue;
         a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
         const size_t lds = co_lds_floats(a.np, a.ldc, H, false) * sizeof(float);
@@ -797,7 +904,7 @@ __global__ __launch_bounds__(256) void k_zero_dead_rows(const int* __restrict__ 
     for (int c = l; c < ZC; c += 64) dz[c] = 0.f;
 }
 
-extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B) {
+extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B, int nbig, int np_big) {
     const int ZC = bmp_coattn_zcols(o, H);
     const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
     const int Nm = N1 > N2 ? N1 : N2;
@@ -815,8 +922,8 @@ extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d
         const size_t s5 = bmp_wgrad_multi_ws_floats(g, 3);
         if (s5 > slab) slab = s5;
     }
-    // dQ2 [N2 x d] | dZ1 [N1 x ZC] | dZ2 [N2 x ZC] | dpart [B x (2H+1)] | slab
-    return (size_t)N2 * d + (size_t)(N1 + N2) * ZC + (size_t)B * (2 * H + 1) + slab;
+    // dQ2 [N2 x d] | dZ1 [N1 x ZC] | dZ2 [N2 x ZC] | dpart [B x (2H+1)] | slab | the oversized class's images
+    return (size_t)N2 * d + (size_t)(N1 + N2) * ZC + (size_t)B * (2 * H + 1) + slab + 16 + bmp_coattn_big_ws_floats(np_big, H, o, nbig, 1);
 }
 
 // Backward.  Wb [d x d] = W natural ([p][q]) (dX2 += dQ2 . W); ZW1/ZW2 [ZC x d] = transposes of ZW*T.
@@ -825,7 +932,7 @@ extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d
 extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
                                   int n_tiles2, int d, int o, int H, int act, int mode, const float* w1, const int* r1,
                                   const int* n1, const float* w2, const int* r2, const int* n2, const long long* coff,
-                                  int B, const int* order, int n32, int n64, int n96, int n128, const float* Wb,
+                                  int B, const int* order, int n32, int n64, int n96, int n128, int nbig, int np_big, const float* Wb,
                                   const float* ZW1, const float* ZW2, const float* wa1,
                                   const float* wa2, const float* Q2, const float* Z1, const float* Z2, const float* Cbuf,
                                   const float* H1, const float* H2, const float* al1, const float* al2, float* dX1,
@@ -833,8 +940,9 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
                                   size_t ws_floats, hipStream_t st, hipStream_t st_w, const int* row_mol1,
                                   const int* row_mol2) {
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
-    BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && n32 + n64 + n96 + n128 == B);
-    BMP_REQUIRE(ws_floats >= bmp_coattn_nie_bwd_ws_floats(n_tiles1, n_tiles2, d, o, H, B));
+    BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && nbig >= 0 && n32 + n64 + n96 + n128 + nbig == B);
+    BMP_REQUIRE(nbig == 0 || np_big > CO_MAXN);
+    BMP_REQUIRE(ws_floats >= bmp_coattn_nie_bwd_ws_floats(n_tiles1, n_tiles2, d, o, H, B, nbig, np_big));
     const int ZC = bmp_coattn_zcols(o, H);
     const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
     float* dQ2 = ws;
@@ -892,6 +1000,17 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
 #undef CO_BWD_LAUNCH
             BMP_LAUNCH_CHECK();
             off += cnt[c];
+        }
+        if (nbig > 0) {   // the oversized class (order: classes ascending, so these pairs come last): out of the workspace's tail
+            const size_t big_fl = bmp_coattn_big_ws_floats(np_big, H, o, nbig, 1);
+            float* big = ws + (((ws_floats - big_fl) / 4) * 4);
+            a.np = co_big_np(np_big); a.ldc = a.np + 1; a.order_off = off;
+            a.big_ws = big; a.big_stride = (long long)co_big_stride(np_big, H, true, o);
+            BmpProfScope prof(BMP_KCLS_COATTN, 0.0, 0.0, st, BMP_KID_COATTN_BWD);
+            if (H == 8) hipLaunchKernelGGL((k_coattn_bwd<8, 512, true>), dim3(nbig), dim3(512), 0, st, a);
+            else if (H == 4) hipLaunchKernelGGL((k_coattn_bwd<4, 512, true>), dim3(nbig), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_coattn_bwd<0, 512, true>), dim3(nbig), dim3(512), 0, st, a);
+            BMP_LAUNCH_CHECK();
         }
         if (beside && (rc = bmp_stream_after(st_w, st))) return rc;
     }

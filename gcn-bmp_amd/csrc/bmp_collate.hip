@@ -63,7 +63,7 @@ extern "C" int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n
         BMP_REQUIRE(mids[i] >= 0 && mids[i] < n_store);
         mid[i] = mids[i];
         nrows[i] = st_nrows[mids[i]];
-        BMP_REQUIRE(nrows[i] >= 1 && nrows[i] <= R);
+        BMP_REQUIRE(nrows[i] >= 1);
         n_real += nrows[i] - 1;
         n_edges += st_nedges[mids[i]];
         max_rows = std::max(max_rows, nrows[i]);
@@ -71,7 +71,10 @@ extern "C" int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n
     }
     int tile0 = 0;
     side_tiles[0] = 0;
-    std::vector<int> order, cnt(R + 2);
+    // An instance of more than R rows (a molecule of more than R - 1 atoms: the reference's preprocessor has no size limit,
+    // train_ddi_modify.py:256) takes ceil(rows / R) whole consecutive tiles of its own at the head of its side, in the stable
+    // decreasing-size order; the rest of its last tile stays dead.  Same placement as bmp.packed._bin_pack.
+    std::vector<int> order, cnt(R + 2), bigs;
     for (int s = 0; s < n_sides; ++s) {
         const int lo = side_ptr[s], hi = side_ptr[s + 1], n = hi - lo;
         BMP_REQUIRE(n >= 1);
@@ -79,24 +82,37 @@ extern "C" int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n
         for (int i = lo; i < hi; ++i) A = std::max(A, nrows[i] - 1);
         if (pad_to) { BMP_REQUIRE(pad_to[s] >= A); A = pad_to[s]; }
         for (int i = lo; i < hi; ++i) padw[i] = A - (nrows[i] - 1);
+        // oversized instances first: stable by decreasing size
+        bigs.clear();
+        for (int i = lo; i < hi; ++i) if (nrows[i] > R) bigs.push_back(i);
+        std::stable_sort(bigs.begin(), bigs.end(), [&](int a, int b) { return nrows[a] > nrows[b]; });
+        for (int it : bigs) {
+            const int k = (nrows[it] + R - 1) / R;
+            row0[it] = tile0 * R;
+            ndead[it] = k * R - nrows[it];
+            tile0 += k;
+        }
+        const int n_small = n - (int)bigs.size();
         // stable order by decreasing size (counting sort; == numpy argsort(-sizes, kind="stable"))
         std::fill(cnt.begin(), cnt.end(), 0);
-        for (int i = lo; i < hi; ++i) ++cnt[R - nrows[i] + 1];
+        for (int i = lo; i < hi; ++i) if (nrows[i] <= R) ++cnt[R - nrows[i] + 1];
         for (int k = 1; k <= R + 1; ++k) cnt[k] += cnt[k - 1];
-        order.assign(n, 0);
-        for (int i = lo; i < hi; ++i) order[cnt[R - nrows[i]]++] = i;
-        FirstFit ff(n, R);
-        std::vector<int> last(n, -1);
+        order.assign(n_small, 0);
+        for (int i = lo; i < hi; ++i) if (nrows[i] <= R) order[cnt[R - nrows[i]]++] = i;
         int nb = 0;
-        for (int q = 0; q < n; ++q) {
-            const int it = order[q];
-            int off;
-            const int b = ff.take(nrows[it], &off, R);
-            row0[it] = (tile0 + b) * R + off;
-            last[b] = it;                       // offsets grow with every placement: the latest item is the tile's last
-            nb = std::max(nb, b + 1);
+        if (n_small > 0) {
+            FirstFit ff(n_small, R);
+            std::vector<int> last(n_small, -1);
+            for (int q = 0; q < n_small; ++q) {
+                const int it = order[q];
+                int off;
+                const int b = ff.take(nrows[it], &off, R);
+                row0[it] = (tile0 + b) * R + off;
+                last[b] = it;                   // offsets grow with every placement: the latest item is the tile's last
+                nb = std::max(nb, b + 1);
+            }
+            for (int b = 0; b < nb; ++b) ndead[last[b]] = ff.cap(b);
         }
-        for (int b = 0; b < nb; ++b) ndead[last[b]] = ff.cap(b);
         tile0 += nb;
         side_tiles[s + 1] = tile0;
     }
@@ -118,8 +134,10 @@ extern "C" int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n
 // table: what bmp/coattention.py:pair_rows computes with numpy.  meta (8 * B int32 entries, 8-byte aligned):
 //   coff[B] as int64 (= 2B int32) | r1[B] | n1[B] | r2[B] (relative to side 2's first row) | n2[B] |
 //   order[B] (size classes ascending, stable) | order_f[B] (size classes descending, stable).
-// counts [4]: pairs per size class ceil(max(n1, n2) / 32) - 1;  ctotal: floats of all C blocks
-// (C [n2 x n1] and the softmax statistics of its rows and columns, bmp_coattn_nie_fwd).
+// counts [6]: pairs per size class ceil(max(n1, n2) / 32) - 1 for classes 0..3; counts[4]: pairs with a molecule of more than
+// 128 rows (the pair kernels' fifth class, which works out of global memory); counts[5]: the largest row count among those
+// pairs (0 without any).  ctotal: floats of all C blocks (C [n2 x n1] and the softmax statistics of its rows and columns,
+// bmp_coattn_nie_fwd).
 extern "C" int bmp_collate_pair_meta(const int* tab, int I, int B, int side1_tiles, int R, int* meta, int* counts,
                                      long long* ctotal) {
     BMP_REQUIRE(tab && meta && counts && ctotal && B >= 1 && I == 2 * B);
@@ -128,6 +146,7 @@ extern "C" int bmp_collate_pair_meta(const int* tab, int I, int B, int side1_til
     int* r1 = meta + 2 * (size_t)B; int* n1 = r1 + B; int* r2 = n1 + B; int* n2 = r2 + B; int* ord = n2 + B; int* ordf = ord + B;
     long long c = 0;
     int cnt[5] = {0, 0, 0, 0, 0};
+    int maxbig = 0;
     std::vector<int> cls(B);
     for (int p = 0; p < B; ++p) {
         const int a = nrows[p], b = nrows[B + p];
@@ -135,17 +154,19 @@ extern "C" int bmp_collate_pair_meta(const int* tab, int I, int B, int side1_til
         c += (long long)a * b + 2ll * (a + b);
         r1[p] = row0[p]; n1[p] = a;
         r2[p] = row0[B + p] - side1_tiles * R; n2[p] = b;
-        const int k = (std::max(a, b) + 31) / 32 - 1;
-        BMP_REQUIRE(k >= 0 && k < 4);
+        int k = (std::max(a, b) + 31) / 32 - 1;
+        BMP_REQUIRE(k >= 0);
+        if (k > 3) { k = 4; maxbig = std::max(maxbig, std::max(a, b)); }
         cls[p] = k; ++cnt[k];
     }
-    int start[4], startf[4];
+    int start[5], startf[5];
     start[0] = 0;
-    for (int k = 1; k < 4; ++k) start[k] = start[k - 1] + cnt[k - 1];
-    startf[3] = 0;
-    for (int k = 2; k >= 0; --k) startf[k] = startf[k + 1] + cnt[k + 1];
+    for (int k = 1; k < 5; ++k) start[k] = start[k - 1] + cnt[k - 1];
+    startf[4] = 0;
+    for (int k = 3; k >= 0; --k) startf[k] = startf[k + 1] + cnt[k + 1];
     for (int p = 0; p < B; ++p) { ord[start[cls[p]]++] = p; ordf[startf[cls[p]]++] = p; }
-    for (int k = 0; k < 4; ++k) counts[k] = cnt[k];
+    for (int k = 0; k < 5; ++k) counts[k] = cnt[k];
+    counts[5] = maxbig;
     *ctotal = c;
     return 0;
 }

@@ -211,24 +211,29 @@ int bmp_rowcorr_bwd(const float* de, const float* a, int o, const float* q, cons
  * [r1[b], r1[b]+n1[b]) of X1 with rows [r2[b], r2[b]+n2[b]) of X2; w1/w2 are the row multiplicities.
  * WbT[q*d+p] = W[p][q] (bilinear form), ZW{1,2}T [d x ZC] = [Wj^T | Wl_k^T | V_k | 0] with
  * ZC = bmp_coattn_zcols(o, H), zb [ZC] = [bj | 0], wa{1,2} [H], cbias [1].
- * `order` lists the pair ids grouped by size class (max(n1,n2) <= 32, 64, 96, 128) with n32..n128 the class
- * counts (sum = B): one launch per class, LDS sized by the class.
+ * `order` lists the pair ids grouped by size class (max(n1,n2) <= 32, 64, 96, 128, and `nbig` pairs with a molecule of
+ * more than 128 rows: the reference's preprocessor has no size limit, train_ddi_modify.py:256) with n32..n128, nbig the
+ * class counts (sum = B): one launch per class, LDS sized by the class -- the forward takes the classes in DESCENDING size
+ * (oversized pairs first), the backward ascending.  The oversized class runs the same program out of a global workspace
+ * (bmp_coattn_big_ws_floats; np_big = the largest row count among its pairs; ws_big may be NULL when nbig == 0).
  * Saves Q2 [N2 x d], Z1/Z2 [N x ZC], H1/H2 [N x H], al1/al2 [N] and Cbuf: pair b owns n2*n1 + 2*(n1 + n2) floats at
  * coff[b] -- C (n2 x n1, row-major), then the softmax statistics of C the backward reloads: cmax [n1], 1/D2 [n1]
  * (column softmax over side-2 atoms), rmax [n2], 1/D1 [n2] (row softmax over side-1 atoms). */
 int bmp_coattn_zcols(int o, int H);
 int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2, int n_tiles2, int d, int o, int H, int act, int mode,
                        const float* w1, const int* r1, const int* n1, const float* w2, const int* r2, const int* n2,
-                       const long long* coff, int B, const int* order, int n32, int n64, int n96, int n128,
+                       const long long* coff, int B, const int* order, int n32, int n64, int n96, int n128, int nbig, int np_big,
                        const float* WbT, const float* ZW1T, const float* ZW2T,
                        const float* zb, const float* wa1, const float* wa2, const float* cbias, float* Q2, float* Z1,
                        float* Z2, float* Cbuf, float* H1, float* H2, float* al1, float* al2, float* out1, float* out2,
-                       bmp_stream_t stream);
-size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B);
+                       float* ws_big, size_t ws_big_floats, bmp_stream_t stream);
+size_t bmp_coattn_big_ws_floats(int np_big, int H, int o, int nbig, int backward);
+size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B, int nbig, int np_big);
 int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, int n_tiles1, const float* X2,
                        int n_tiles2, int d, int o, int H, int act, int mode, const float* w1, const int* r1, const int* n1,
                        const float* w2, const int* r2, const int* n2, const long long* coff, int B, const int* order,
-                       int n32, int n64, int n96, int n128, const float* Wb, const float* ZW1, const float* ZW2, const float* wa1, const float* wa2,
+                       int n32, int n64, int n96, int n128, int nbig, int np_big, const float* Wb, const float* ZW1, const float* ZW2,
+                       const float* wa1, const float* wa2,
                        const float* Q2, const float* Z1, const float* Z2, const float* Cbuf, const float* H1,
                        const float* H2, const float* al1, const float* al2, float* dX1, float* dX2, float* dWbT,
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
@@ -267,7 +272,8 @@ int bmp_dense_to_csr(const float* adj, int mb, int A, const int* rowmap, const i
  * batch one after the other (side_ptr [n_sides + 1]); pad_to [n_sides] or NULL.  tab (out, 6 * I int32):
  * row0 | nrows | mid | ebase | padw | ndead.  side_tiles (out) [n_sides + 1]; totals (out) [4]: n_tiles, n_edges,
  * n_real_atoms, max rows of an instance.  meta (out, 8 * B int32, 8-byte aligned): coff (int64) | r1 | n1 | r2 | n2 |
- * order | order_f as bmp_coattn_nie_fwd/_bwd take them; counts [4]; ctotal.
+ * order | order_f as bmp_coattn_nie_fwd/_bwd take them; counts [6]: the five size classes and np_big; ctotal.
+ * An instance of more than R rows takes ceil(rows / R) whole consecutive tiles at the head of its side.
  * bmp_collate_emit (DEVICE): writes the packed batch of bmp/packed.py from the plan table and the store's arrays
  * (st_rowoff / st_eoff [M + 1], st_atom, per-row local entry ends st_rend / st_rendT, local entries st_col / st_colT =
  * local row << 2 | bond type).  Bit-identical to the host packer. */

@@ -61,9 +61,12 @@ def test_plan_and_emit_equal_host_packer(n_mols, B, seed, pad_to):
 
 def test_plan_placement_is_first_fit_decreasing():
     rs = np.random.RandomState(5)
-    for trial in range(20):
+    for trial in range(24):
         n = rs.randint(1, 400)
         sizes = rs.randint(1, 129, size=n).astype(np.int64)
+        if trial % 3 == 2:          # a few molecules larger than a tile: whole consecutive tiles at the head of the side
+            big = rs.choice(n, min(n, rs.randint(1, 5)), replace=False)
+            sizes[big] = rs.randint(129, 700, size=len(big))
         bins, offs, nb = packed._bin_pack(sizes, 128)
         nedges = np.zeros(n, np.int32)
         tab, side_tiles, _sm, n_tiles, *_ = packed.collate_plan_host(sizes.astype(np.int32), nedges, [np.arange(n)])
@@ -79,30 +82,32 @@ def test_pair_meta_equals_numpy_form():
     from bmp import _lib
     from bmp.coattention import _cbuf_floats, _size_classes
     store = synth.make_store(200, seed=3, n_lo=1, n_hi=120, n_mean=30)
+    store[7] = synth.make_store(1, seed=8, n_lo=140, n_hi=141, n_mean=140)[0]        # two molecules larger than a tile
+    store[90] = synth.make_store(1, seed=9, n_lo=300, n_hi=301, n_mean=300)[0]
     ms = packed.MolStore(store)
     ds = packed.DeviceMolStore(ms, "cpu")
     rs = np.random.RandomState(1)
     B = 333
     sides = [rs.randint(0, 200, B), rs.randint(0, 200, B)]
     tab, side_tiles, *_ = packed.collate_plan_host(ds.st_nrows, ds.st_nedges, sides)
-    meta = np.zeros(8 * B, np.int32); cnt = np.zeros(4, np.int32); ct = np.zeros(1, np.int64)
+    meta = np.zeros(8 * B, np.int32); cnt = np.zeros(6, np.int32); ct = np.zeros(1, np.int64)
     _lib.check(_lib.lib().bmp_collate_pair_meta(packed._i32p(tab), 2 * B, B, side_tiles[1], 128, packed._i32p(meta),
                                                 packed._i32p(cnt), packed._i32p(ct)), "pair_meta")
     nr = tab[2 * B:4 * B].astype(np.int64)
     nr1, nr2 = nr[:B], nr[B:]
     coff = np.concatenate(([0], np.cumsum(_cbuf_floats(nr1, nr2))))
-    order, counts, order_f, counts_f = _size_classes(nr1, nr2, "cpu")
+    order, counts, order_f, counts_f, np_big = _size_classes(nr1, nr2, "cpu")
     assert np.array_equal(meta[:2 * B].view(np.int64), coff[:-1]) and ct[0] == coff[-1]
     assert np.array_equal(meta[2 * B:3 * B], tab[:B]) and np.array_equal(meta[3 * B:4 * B], nr1)
     assert np.array_equal(meta[4 * B:5 * B], tab[B:2 * B] - side_tiles[1] * 128) and np.array_equal(meta[5 * B:6 * B], nr2)
     assert np.array_equal(meta[6 * B:7 * B], order.numpy()) and np.array_equal(meta[7 * B:], order_f.numpy())
-    assert list(cnt) == counts
+    assert list(cnt[:5]) == counts and cnt[5] == np_big and counts[4] > 0 and np_big >= 300
 
 
 def test_plan_rejects_bad_input():
     nrows = np.array([5, 200], np.int32); ne = np.zeros(2, np.int32)
-    with pytest.raises(ValueError):
-        packed.collate_plan_host(nrows, ne, [np.array([1])])              # does not fit a tile
+    tab, st, *_ = packed.collate_plan_host(nrows, ne, [np.array([1, 0])])     # larger than a tile: two whole tiles, then the rest
+    assert st == (0, 3) and list(tab[:2]) == [0, 256] and list(tab[10:12]) == [56, 123]
     with pytest.raises(ValueError):
         packed.collate_plan_host(nrows, ne, [np.array([2])])              # molecule index out of range
     with pytest.raises(ValueError):
@@ -122,6 +127,8 @@ def test_plan_equals_host_packer_on_random_stores():
         mols = []
         for _ in range(n_mols):
             n = int(rs.randint(1, 128))                      # up to 127 atoms: with the pad row exactly a full tile
+            if rs.uniform() < 0.04:
+                n = int(rs.randint(128, 420))                # ... and now and then a molecule larger than a tile
             atoms = rs.randint(1, 100, size=n).astype(np.int32)
             nb = int(rs.randint(0, 2 * n))
             i, j = rs.randint(0, n, nb), rs.randint(0, n, nb)

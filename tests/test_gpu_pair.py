@@ -242,7 +242,8 @@ def test_coarse_coattention_pair(pairs, attn, joint):
     from bmp.snapshot import load_param_dict, grad_dict
     store, i1, i2, pb = pairs
     d = 16
-    p = O.make_pair_params(41, hidden_dim=d, out_dim=d, n_layers=2, attn=attn, dtype=torch.float64)
+    # BiMPM is built with head = fp_out_dim (train_binary.py:253-256), the others with the builder's head = 8
+    p = O.make_pair_params(41, hidden_dim=d, out_dim=d, n_layers=2, attn=attn, dtype=torch.float64, head=(d if attn == "bimpm" else 8))
     p = {k: v.requires_grad_() for k, v in p.items()}
     a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
     y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn=attn)
@@ -263,7 +264,10 @@ def test_coarse_coattention_pair(pairs, attn, joint):
         floor = p["attn/energy_layers_2/0/W"].grad.abs().max().item() if name == "attn/energy_layers_2/0/b" else 1e-6
         if attn == "circ":       # gate and value both come from j_layer: gradients are sums of o-term products
             floor = 1e-4 * float(ref.abs().max())
-        close(gr, ref, f"grad {name}", floor=floor)
+        # BiMPM with 16 perspectives on these molecules has near-ties in its max selections: the ORACLE ITSELF evaluated in
+        # float32 differs from its float64 gradients by up to 1.3e-3 here (W of the GRU; 7e-4 on embed.W), while its logits
+        # agree to 2e-6 -- an argmax flips, the gradient takes the other branch.  The HIP path lands at 2.4e-4.
+        close(gr, ref, f"grad {name}", floor=floor, **(dict(tol=2e-3) if attn == "bimpm" else {}))
 
 
 @pytest.mark.parametrize("attn", ["deep", "extreme-deep", "fourier"])

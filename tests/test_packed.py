@@ -99,9 +99,14 @@ def test_empty_and_single():
     ms = packed.MolStore([synth.Molecule(np.array([11], np.int32), np.zeros((0, 3), np.int32))])
     pb = packed.pack_from_store(ms, [np.array([0])], R=32, with_dense_map=True)
     assert pb.n_tiles == 1 and pb.n_edges == 0 and int(pb.csr_ptr[-1]) == 0
-    with pytest.raises(ValueError):
-        big = synth.Molecule(np.full(40, 6, np.int32), np.zeros((0, 3), np.int32))
-        packed.pack_from_store(packed.MolStore([big]), [np.array([0])], R=32)
+    # a molecule larger than a tile (the reference's preprocessor has no size limit, train_ddi_modify.py:256): whole
+    # consecutive tiles of its own at the head of the side, the smaller ones behind it
+    big = synth.Molecule(np.full(40, 6, np.int32), np.zeros((0, 3), np.int32))
+    pbb = packed.pack_from_store(packed.MolStore([ms_mol := synth.Molecule(np.array([11], np.int32), np.zeros((0, 3), np.int32)), big]),
+                                 [np.array([0, 1, 0])], R=32, with_dense_map=True)
+    assert pbb.oversized and pbb.max_rows_per_mol == 41 and pbb.n_tiles == 3
+    assert pbb.mol_row0.tolist() == [64, 0, 66] and pbb.mol_nrows.tolist() == [2, 41, 2]
+    assert float(pbb.row_w.sum()) == 3 * 40 and int((pbb.row_mol >= 0).sum()) == 45
 
 
 def test_bin_pack_fill():
@@ -183,3 +188,36 @@ def test_packed_fourier_nie_matches_dense_oracle(store):
     assert torch.allclose(c1, g1, atol=1e-12) and torch.allclose(c2, g2, atol=1e-12)
     n1, n2 = O.nie_coattention(p, at1, at2, prefix="attn/")
     assert not torch.allclose(g1, n1, atol=1e-3)                   # and it is not the plain Nie energy
+
+
+def test_oversized_molecules_match_dense_oracle_with_grads():
+    """Molecules larger than a tile (here R = 32: 33..80 atoms; SURVEY.md 8(a) R0, train_ddi_modify.py:256 sets no limit):
+    the packed restatement -- gathers over absolute rows, per-molecule segment sums, pair blocks of any size -- against
+    the dense float64 oracle: molecule vectors, atom states, co-attention outputs and every gradient."""
+    store = synth.make_store(6, seed=21, n_lo=2, n_hi=20, n_mean=9) + synth.make_store(3, seed=22, n_lo=33, n_hi=80, n_mean=50)
+    assert max(m.n for m in store) > 32
+    ms = packed.MolStore(store)
+    i1 = np.array([0, 6, 7, 3, 8, 1, 6]); i2 = np.array([7, 2, 6, 8, 8, 4, 0])
+    p = O.make_pair_params(777, hidden_dim=8, out_dim=8, n_layers=2, attn="nie", dtype=torch.float64)
+    p = {k: v.requires_grad_() for k, v in p.items()}
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    pb = packed.pack_from_store(ms, [i1, i2], R=32, with_dense_map=True)
+    assert pb.oversized and pb.n_tiles > 10
+    # dense <-> packed round trip of the index work stays exact
+    for side, (a, j) in enumerate(((a1, j1), (a2, j2))):
+        ad, jd = packed.unpack_to_dense(pb, side)
+        assert np.array_equal(ad, a) and np.array_equal(jd, j)
+    y, g1, g2 = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), n_layers=2, attn="nie")
+    ge1, at1 = O.ggnn_forward(p, T(a1), T(j1).double(), 2, prefix="graph_conv/")
+    g, h = PR.ggnn_forward(p, pb, 2, prefix="graph_conv/")
+    assert torch.allclose(g[:7], ge1, atol=1e-11) and torch.allclose(pb.to_dense(h, 0), at1, atol=1e-12)
+    c1, c2 = PR.nie_coattention(p, pb, h, np.arange(7), 7 + np.arange(7), prefix="attn/")
+    assert torch.allclose(c1, g1, atol=1e-12) and torch.allclose(c2, g2, atol=1e-12)
+    names = [n for n in sorted(p) if not n.startswith("mlp/")]
+    w1 = torch.randn(7, 8, dtype=torch.float64); w2 = torch.randn(7, 8, dtype=torch.float64)
+    gp = torch.autograd.grad((c1 * w1).sum() + (c2 * w2).sum(), [p[n] for n in names], allow_unused=True)
+    gd = torch.autograd.grad((g1 * w1).sum() + (g2 * w2).sum(), [p[n] for n in names], allow_unused=True)
+    for n, x, y_ in zip(names, gp, gd):
+        assert (x is None) == (y_ is None), n
+        if x is not None:
+            assert torch.allclose(x, y_, rtol=1e-9, atol=1e-11), n
