@@ -74,6 +74,8 @@ SIGNATURES = {
     "bmp_bimpm_ws_floats": (_Z, [_I, _I, _I, _I, _I]),
     "bmp_bimpm_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "bmp_bimpm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bmp_molrows_expand": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "bmp_molrows_reduce": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmp_rescale_adj": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),

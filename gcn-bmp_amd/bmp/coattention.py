@@ -171,7 +171,7 @@ class PNieFn(Function):
     G: dWbT, dZW1T, dZW2T, dzb, dwa."""
 
     @staticmethod
-    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode, state=None, rm1=None, rm2=None):
+    def forward(ctx, X1, X2, W, G, w1, w2, meta, d, o, H, act, mode, state=None, rm1=None, rm2=None, infer=False):
         L = _lib.lib()
         dev = X1.device
         ctx.state = state
@@ -187,8 +187,11 @@ class PNieFn(Function):
         N1, N2 = X1.shape[0], X2.shape[0]
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         Q2, Z1, Z2 = f(N2, d), f(N1, ZC), f(N2, ZC)
-        Cbuf = f(max(meta["ctotal"], 1))
-        H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)
+        if infer:         # forward-only evaluation (predict): C, its statistics, H and alpha are the backward's and are not kept
+            Cbuf = H1 = H2 = al1 = al2 = None
+        else:
+            Cbuf = f(max(meta["ctotal"], 1))
+            H1, H2, al1, al2 = f(N1, H), f(N2, H), f(N1), f(N2)
         out1, out2 = f(B, o), f(B, o)
         wsb, nwsb = _big_ws(meta, H, o, dev)
         check(L.bmp_coattn_nie_fwd(ptr(X1), T1, ptr(X2), T2, d, o, H, act, mode, ptr(w1), ptr(meta["r1"]), ptr(meta["n1"]),
@@ -226,8 +229,8 @@ class PNieFn(Function):
                                    ptr(ws), nws, stream(), _side_handle(ctx.state, (X1, X2, ws)), ptr(ctx.rm[0]), ptr(ctx.rm[1])),
               "bmp_coattn_nie_bwd")
         if ctx.joint:
-            return (dX,) + (None,) * 14
-        return (dX1, dX2) + (None,) * 13
+            return (dX,) + (None,) * 15
+        return (dX1, dX2) + (None,) * 14
 
 
 class _FinePlanMixin:
@@ -268,7 +271,7 @@ class _FinePlanMixin:
             if rm1 is not None:
                 rm1, rm2 = rm1[:n1], rm1[n1:]
         return PNieFn.apply(X1, X2, P, G, w1, w2, meta, self.hidden_dim, self.out_dim, self._heads(),
-                            ACT[self.activation], mode, state, rm1, rm2)
+                            ACT[self.activation], mode, state, rm1, rm2, not torch.is_grad_enabled())
 
 
 class NieFineCoattention(_FinePlanMixin, nn.Module):

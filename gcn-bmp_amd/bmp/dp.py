@@ -129,6 +129,14 @@ class FlatAdam:
             for mod in hooked:
                 mod._fast = None
 
+    def functional_predict(self, *args, **kwargs):
+        """The evaluation callers' ``predict`` (eval_coattention.py:103-124; training/extensions/batch_evaluator.py:49-100 runs it
+        over the train and validation sets every epoch) on the planned path: logits and the two molecule vectors handed to the
+        link predictor, under no-backprop.  The kernels then keep nothing for a backward (no m / r|z / c / ij / C stores)."""
+        with torch.no_grad():
+            y = self.functional_forward(*args, **kwargs)
+        return y, (getattr(self.module, "g1", None), getattr(self.module, "g2", None))
+
     def _param_slots(self):
         """[((module._parameters, name, parameter), index into self.params)] over every registration of a flattened
         parameter in the module tree."""

@@ -302,19 +302,20 @@ def flush_deferred(state) -> None:
             launch()
 
 
-def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o, st=None, out=None):
+def _readout_fwd(h, h0, pb, WT, WTp, b, act_j, o, st=None, out=None, infer=False):
     """The readout forward: one kernel per tile when the shape allows (WTp = pack_k4(WT), made here if not given),
-    else row GEMM + segment sum.  Returns (ij, g)."""
+    else row GEMM + segment sum.  Returns (ij, g); ``infer`` (forward-only evaluation): the tile kernel keeps no ij."""
     L = _lib.lib()
     st = stream() if st is None else st
     N, d = h.shape
     d0 = 0 if h0 is None else h0.shape[1]
+    tile = pb.row_mol is not None and not pb.oversized and bool(L.bmp_readout_tile_supported(d, d0, o))
     if out is not None:
         ij, g = out
     else:
-        ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+        ij = None if (infer and tile) else torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
         g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
-    if pb.row_mol is not None and not pb.oversized and L.bmp_readout_tile_supported(d, d0, o):
+    if tile:
         if WTp is None:
             WTp = pack_k4(WT)
         check(L.bmp_readout_tile_fwd(ptr(h), ptr(h0), pb.n_tiles, d, ptr(WTp), ptr(b), act_j, ptr(pb.row_w), ptr(pb.row_mol),
@@ -572,9 +573,12 @@ class PEmbedFn(Function):
         return None, None, None, None, None
 
 
-def step_buffers(N: int, d: int, device):
-    """(m, rz, c, hout) of one fused propagation step."""
+def step_buffers(N: int, d: int, device, infer: bool = False):
+    """(m, rz, c, hout) of one fused propagation step.  ``infer`` (forward-only evaluation under no-backprop,
+    train_binary.py:120-127): m, rz and c -- the backward's inputs -- are not kept (None: the kernel skips their stores)."""
     f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+    if infer:
+        return None, None, None, f(N, d)
     return f(N, d), f(N, 2 * d), f(N, d), f(N, d)
 
 
@@ -588,7 +592,7 @@ class PStepFn(Function):
         require_rows(h, "step: h")
         _check_pb(pb, h)
         N, d = h.shape
-        m, rz, c, hout = bufs if bufs is not None else step_buffers(N, d, h.device)
+        m, rz, c, hout = bufs if bufs is not None else step_buffers(N, d, h.device)          # m = rz = c = None: forward only
         for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                       ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
@@ -631,7 +635,7 @@ class PReadoutFn(Function):
     joined (LayoutPlan.collect / prepare) and must not be differentiated."""
 
     @staticmethod
-    def forward(ctx, h, h0, pb, W, G, act_j, state, off_chain=False):
+    def forward(ctx, h, h0, pb, W, G, act_j, state, off_chain=False, infer=False):
         L = _lib.lib()
         require_rows(h, "readout: h")
         _check_pb(pb, h)
@@ -645,7 +649,8 @@ class PReadoutFn(Function):
         if side is not None:
             # enqueued LATER (flush_deferred: once the co-attention's forward launches are in their queue): launched here,
             # its 455 one-per-CU workgroups take the CUs before the chain's next launches get to them
-            ij = torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+            tile = pb.row_mol is not None and not pb.oversized and bool(L.bmp_readout_tile_supported(d, d0, o))
+            ij = None if (infer and tile) else torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
             g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
 
             def launch():
@@ -659,7 +664,7 @@ class PReadoutFn(Function):
                 launch()
             return g
         _register(state, "ro")
-        ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o)
+        ij, g = _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o, infer=infer)
         ctx.save_for_backward(h, ij, *([h0] if h0 is not None else []))
         ctx.pb, ctx.W, ctx.G, ctx.act_j, ctx.o = pb, W, G, act_j, o
         return g
@@ -686,7 +691,7 @@ class PReadoutFn(Function):
                                 ptr(pb.row_w), ptr(pb.mol_row0), ptr(pb.mol_nrows), pb.n_mols, ptr(dh), ptr(dh0),
                                 ptr(G["dWT"]), ptr(G.get("db")), acc, ptr(ws), nws, stream(),
                                 _side_handle(ctx.state, (h, h0, ws))), "bmp_readout_bwd")
-        return dh, dh0, None, None, None, None, None, None
+        return dh, dh0, None, None, None, None, None, None, None
 
 
 class PGRUFn(Function):
@@ -778,9 +783,10 @@ def rel_layer_supported(d_in: int, d_out: int) -> bool:
     return bool(_lib.lib().bmp_relgcn_layer_supported(int(d_in), int(d_out)))
 
 
-def rel_buffers(N: int, d: int, device):
-    """(out, wdeg) of one fused RelGCN layer."""
-    return torch.empty(N, d, dtype=torch.float32, device=device), torch.empty(N, 4, dtype=torch.float32, device=device)
+def rel_buffers(N: int, d: int, device, infer: bool = False):
+    """(out, wdeg) of one fused RelGCN layer; ``infer``: wdeg (the backward's operand) is not kept."""
+    return (torch.empty(N, d, dtype=torch.float32, device=device),
+            None if infer else torch.empty(N, 4, dtype=torch.float32, device=device))
 
 
 def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None, bufs=None):

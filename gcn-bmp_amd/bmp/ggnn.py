@@ -382,7 +382,8 @@ class GGNN(nn.Module):
                                        getattr(self, "_readout_off_chain", False))
         # every step's outputs first, then the two chains of tiles are opened ONCE (Fn.fork_parts) and run to the join
         # without another cross-stream wait
-        bufs = [Fn.step_buffers(h.shape[0], self.hidden_dim, h.device) for _ in range(self.n_layers)]
+        infer = not torch.is_grad_enabled()      # predict under no-backprop: nothing is kept for a backward
+        bufs = [Fn.step_buffers(h.shape[0], self.hidden_dim, h.device, infer) for _ in range(self.n_layers)]
         Fn.fork_parts(state, pb)
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
@@ -394,7 +395,7 @@ class GGNN(nn.Module):
         self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
                                    dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
-                                   getattr(self, "_readout_off_chain", False))
+                                   getattr(self, "_readout_off_chain", False), infer)
 
     def forward(self, atom_array, adj=None):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``

@@ -129,6 +129,17 @@ class PartStream:
             cur.wait_stream(s)
 
 
+_SHARED_STREAMS: Dict[tuple, object] = {}
+
+
+def _shared(kind: str, device, make):
+    d = torch.device(device)
+    key = (kind, d.type, d.index if d.index is not None else torch.cuda.current_device())
+    if key not in _SHARED_STREAMS:
+        _SHARED_STREAMS[key] = make()
+    return _SHARED_STREAMS[key]
+
+
 class LayoutPlan:
     """Built for a list of (prefix, module) pairs whose parameters are slices of one flat fp32 buffer.
     A module takes part if it defines ``prepared_layouts()``, ``primary_layouts()``, ``gk_spec()`` and
@@ -171,10 +182,14 @@ class LayoutPlan:
         self.gk = torch.zeros(max(gk_off, 1), dtype=torch.float32, device=device)
         # weight-gradient launches beside the backward chain (functional._on_side); BMP_WGRAD_STREAM=0 keeps them in line
         one = os.environ.get("BMP_ONE_STREAM") == "1"        # profiling: every launch in line on the caller's stream
-        self.side = SideStream(device) if (torch.device(device).type == "cuda" and not one
-                                           and os.environ.get("BMP_WGRAD_STREAM", "1") != "0") else None
-        self.split = PartStream(device, int(os.environ.get("BMP_FWD_CHAINS", "2")) - 2) if (
-            torch.device(device).type == "cuda" and not one and os.environ.get("BMP_FWD_SPLIT", "1") != "0") else None
+        # One side stream and one part stream per DEVICE, shared by every plan of the process (a second model -- another
+        # config of bench.py, an evaluation copy -- must not add streams: the runtime maps streams onto a handful of hardware
+        # queues, and two chains that land on one queue serialise each other).
+        cuda = torch.device(device).type == "cuda"
+        self.side = _shared("side", device, lambda: SideStream(device)) if (
+            cuda and not one and os.environ.get("BMP_WGRAD_STREAM", "1") != "0") else None
+        self.split = _shared("part", device, lambda: PartStream(device, int(os.environ.get("BMP_FWD_CHAINS", "2")) - 2)) if (
+            cuda and not one and os.environ.get("BMP_FWD_SPLIT", "1") != "0") else None
         self.state: Dict[str, dict] = {}
         self._views()
 

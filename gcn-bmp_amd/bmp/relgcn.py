@@ -204,7 +204,8 @@ class RelGCN(nn.Module):
         all_fused = all(self._fused(l) for l in range(len(self.rgcn_convs)))
         bufs = None
         if all_fused:         # every layer's outputs first, then the chains of tiles opened once (Fn.fork_parts)
-            bufs = [Fn.rel_buffers(x.shape[0], self.rgcn_convs[l].out_channels, x.device) for l in range(len(self.rgcn_convs))]
+            infer = not torch.is_grad_enabled()      # predict under no-backprop: nothing is kept for a backward
+            bufs = [Fn.rel_buffers(x.shape[0], self.rgcn_convs[l].out_channels, x.device, infer) for l in range(len(self.rgcn_convs))]
             Fn.fork_parts(state, pb)
         for l in range(len(self.rgcn_convs)):
             if self._fused(l):
@@ -219,7 +220,7 @@ class RelGCN(nn.Module):
         Fn._join_parts(state)                 # fused layers ran as two chains of tiles
         self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
         return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")), dict(dWT=G["ro.dWT"]),
-                                   Fn.ACT["tanh"], state, getattr(self, "_readout_off_chain", False))
+                                   Fn.ACT["tanh"], state, getattr(self, "_readout_off_chain", False), not torch.is_grad_enabled())
 
     def forward(self, h, adj=None):
         """models/relgcn.py:61-73."""

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
             if (i < n2 && j < n1) {
                 const float cv = bmp_act(a.act, acc[reg] + v1j + L.v2s[i] + cb);
                 L.Cs[i * ldc + j] = cv;
-                cg[(size_t)i * n1 + j] = cv;
+                if (a.Cbuf) cg[(size_t)i * n1 + j] = cv;          // (Cbuf == NULL: forward-only evaluation, nothing kept)
             }
         }
     }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     if constexpr (BIG) co_stats_split_big(L, n1, n2, ldc, NT);
     else co_stats_split(L, n1, n2, ldc, Q);
     __syncthreads();
-    {   // the backward reloads these instead of walking C again (17 % of its time): kept behind the pair's C block
+    if (a.Cbuf) {   // the backward reloads these instead of walking C again (17 % of its time): kept behind the pair's C block
         float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
         if constexpr (BIG) {
             for (int j = tid; j < n1; j += NT) { st[j] = L.cmax[j]; st[n1 + j] = L.invD2[j]; }
@@ -332,12 +332,12 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
         if (valid && q == 0) {
             const float* Pm = side1 ? L.P1s : L.P2s;
             const float* wa = side1 ? a.wa1 : a.wa2;
-            float* Hg = side1 ? a.H1 + (size_t)(r1 + me) * H : a.H2 + (size_t)(r2 + me) * H;
+            float* Hg = a.H1 == nullptr ? nullptr : (side1 ? a.H1 + (size_t)(r1 + me) * H : a.H2 + (size_t)(r2 + me) * H);
             float sc = 0.f;
 #pragma unroll
             for (int h = 0; h < HN; ++h) if (h < H) {
                 const float hv = bmp_tanh(Pm[me * H + h] + acc[h]);
-                Hg[h] = hv;
+                if (Hg) Hg[h] = hv;
                 sc += hv * wa[h];
             }
             (side1 ? L.s1 : L.s2)[me] = sc;
@@ -357,11 +357,11 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
         float s = 0.f;
         for (int k = lane; k < n; k += 64) if (ww[k] > 0.f) s += ww[k] * bmp_exp(sc[k] - mx);
         s = wave_sum(s);
-        float* alg = wave == 0 ? a.al1 + r1 : a.al2 + r2;
+        float* alg = a.al1 == nullptr ? nullptr : (wave == 0 ? a.al1 + r1 : a.al2 + r2);
         for (int k = lane; k < n; k += 64) {
             const float al = ww[k] > 0.f ? bmp_exp(sc[k] - mx) / s : 0.f;
             sc[k] = al;
-            alg[k] = al;
+            if (alg) alg[k] = al;
         }
     }
     __syncthreads();
@@ -833,6 +833,9 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
     BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && nbig >= 0 && n32 + n64 + n96 + n128 + nbig == B);
     BMP_REQUIRE(nbig == 0 || (np_big > CO_MAXN && ws_big && ws_big_floats >= bmp_coattn_big_ws_floats(np_big, H, o, nbig, 0)));
+    // forward-only evaluation (predict): Cbuf, H1, H2, al1, al2 -- what the backward reloads -- may be NULL together
+    BMP_REQUIRE((Cbuf != nullptr) == (H1 != nullptr) && (Cbuf != nullptr) == (H2 != nullptr) && (Cbuf != nullptr) == (al1 != nullptr) &&
+                (Cbuf != nullptr) == (al2 != nullptr));
     const int ZC = bmp_coattn_zcols(o, H);
     int rc;
     {   // Q2 = X2 . WbT ; Z1 = X1 . ZW1T + zb ; Z2 = X2 . ZW2T + zb : three projections, one launch

@@ -269,6 +269,9 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     float* Al = As + lrow * LD + col;
 #define LOFF(rb, reg) (((rb) * 32 + ((reg) & 3) + 8 * ((reg) >> 2)) * LD)
 
+    // forward-only evaluation (predict under no-backprop, train_binary.py:120-127): m, r|z and c are the backward's inputs
+    // and are not written when the caller passes no arrays for them
+    const bool save = a.m != nullptr;
     // ---- h tile -> LDS ----
     for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
             const float v = acc_m[0][rb][reg] + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
             Al[LOFF(rb, reg)] = v;
-            acc_st<D>(mo, rb, reg, v);
+            if (save) acc_st<D>(mo, rb, reg, v);
         }
     }
     FZ_GSYNC();
@@ -345,11 +348,11 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         FZ_FOR_ACC {
             const float zv = bmp_sigmoid(acc_g[1][rb][reg] + bz);
             acc_g[1][rb][reg] = zv;
-            acc_st<2 * D>(rzo, rb, reg, zv, D);
+            if (save) acc_st<2 * D>(rzo, rb, reg, zv, D);
             if (!FIRST) {
                 const float rv = bmp_sigmoid(acc_g[0][rb][reg] + br);
                 acc_g[0][rb][reg] = rv;
-                acc_st<2 * D>(rzo, rb, reg, rv, 0);
+                if (save) acc_st<2 * D>(rzo, rb, reg, rv, 0);
             }
         }
     }
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const float zv = acc_g[1][rb][reg];
             float hn = zv * cv;
             if (!FIRST) hn += (1.f - zv) * Hl[LOFF(rb, reg)];
-            acc_st<D>(co, rb, reg, cv);
+            if (save) acc_st<D>(co, rb, reg, cv);
             acc_st<D>(ho, rb, reg, hn);
         }
     }
@@ -646,7 +649,8 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
             acc_st<D>(oo, rb, reg, bmp_act(act, v));
         }
     }
-    if ((tid & 255) < 64) {           // this half's weighted degrees (written by this half's threads, group-synced above)
+    if (a.wdeg != nullptr && (tid & 255) < 64) {   // this half's weighted degrees (written by this half's threads, group-synced
+                                                   // above); the backward's operand: not written in forward-only evaluation
         const int r = grp * 64 + (tid & 255);
         *(f32x4*)(a.wdeg + (size_t)(row0 + r) * 4) = *(const f32x4*)(wds + r * 4);
     }
@@ -825,8 +829,10 @@ __global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
             const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
             const float iv = bmp_sigmoid(acc[0][rb][reg] + bi);
             const float jv = bmp_act(act, acc[1][rb][reg] + bj);
-            acc_st<2 * D>(io, rb, reg, iv, 0);
-            acc_st<2 * D>(io, rb, reg, jv, D);
+            if (a.ij != nullptr) {            // the backward's input: not written in forward-only evaluation
+                acc_st<2 * D>(io, rb, reg, iv, 0);
+                acc_st<2 * D>(io, rb, reg, jv, D);
+            }
             Al[LOFF(rb, reg)] = rws[r] * iv * jv;
         }
     }
@@ -880,11 +886,13 @@ static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
 }
 
 // One GGNN propagation step, forward (models/ggnn.py:215-263): m = message(h), h' = GRU([h, m]).
-// Weight layouts as bmp_msg_fwd / bmp_gru_fwd.  Saves m [N x d], rz [N x 2d], c [N x d].
+// Weight layouts as bmp_msg_fwd / bmp_gru_fwd.  Saves m [N x d], rz [N x 2d], c [N x d] -- or none of them when m, rz and c are
+// all NULL (forward-only evaluation: predict under no-backprop, train_binary.py:120-127).
 extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr,
                                  const int* csr_col, const float* csr_val, const float* WT, const float* bE, const float* AT,
                                  const float* UcT, const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
     BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
+    BMP_REQUIRE((m != nullptr) == (rz != nullptr) && (m != nullptr) == (c != nullptr) && hout != nullptr);
     StepArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;

@@ -285,6 +285,18 @@ int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, const int* st_
                      int* csr_ptr, int* csr_col, float* csr_val, int* csrT_ptr, int* csrT_col, float* csrT_val,
                      bmp_stream_t stream);
 
+/* ---- de-duplicated encoding of a pair batch ("de-duplication caveat": a batch of B pairs holds 2B molecule
+ * instances of at most 544 distinct drugs, setting.py:30; an atom's state depends on its molecule alone, models/ggnn.py:584-654) ----
+ * The encoder runs over the distinct molecules, the co-attention over the per-instance layout; these two index kernels connect
+ * them.  row_mol [N_inst] / urow_mol [N_U]: instance / distinct molecule of every row (-1: none); inst_row0 [I], urow0 [U]: first
+ * rows; uid [I]: distinct molecule of every instance; uptr [U + 1] / uinst: the instances of every distinct molecule, ascending.
+ * bmp_molrows_expand: out[instance row] = hU[its molecule's row] (rows of no instance: 0).  bmp_molrows_reduce:
+ * dhU[row] = sum over the molecule's instances, in that order, of dX[instance row] -- no atomics, bitwise reproducible. */
+int bmp_molrows_expand(const float* hU, int d, const int* row_mol, const int* inst_row0, const int* uid, const int* urow0,
+                       int N_inst, float* out, bmp_stream_t stream);
+int bmp_molrows_reduce(const float* dX, int d, const int* urow_mol, const int* urow0, const int* uptr, const int* uinst,
+                       const int* inst_row0, int N_U, float* dhU, bmp_stream_t stream);
+
 /* rescale_adj -- models/relgcn.py:20-28 on the packed CSR: csr_val_out[e] = csr_val[e] * (1 / deg(source of e)), and the
  * same for the transposed CSR; deg = sum of the source atom's bond values over types and destinations (0 -> 1). */
 int bmp_rescale_adj(const int* csr_col, const float* csr_val, int E, const int* csrT_ptr, const float* csrT_val, int N,

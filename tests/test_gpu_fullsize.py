@@ -209,3 +209,39 @@ def test_planned_no_grad_forward_with_two_chains_is_the_one_chain_forward(world)
     assert torch.isfinite(y_one).all()
     for y in [y0] + outs:
         assert torch.equal(y, y_one)
+
+
+def test_planned_predict_is_the_training_forward_and_matches_the_oracle(world):
+    """The evaluation callers' predict (eval_coattention.py:103-124: logits and the two molecule vectors under no-backprop)
+    on the planned path at full size: the kernels keep nothing for a backward (no m / r|z / c / ij / C stores), yet the
+    logits are bit for bit those of the training-mode forward; six pairs against the oracle's logits and molecule vectors."""
+    from bmp import packed
+    from bmp.dp import FlatAdam
+    from oracle import ref_cpu as O
+    from parity_util import close
+    w = world
+    opt = FlatAdam(w["model"], alpha=0.0)
+    pb = packed.pack_from_store(w["ms"], [w["i1"], w["i2"]], device=w["dev"])
+    y_train = opt.functional_forward(pb).detach().clone()
+    y, (g1, g2) = opt.functional_predict(pb)
+    torch.cuda.synchronize()
+    assert not y.requires_grad and torch.equal(y, y_train)
+    y2, _ = opt.functional_predict(pb)                      # again: nothing stale
+    assert torch.equal(y2, y)
+    n = w["ms"].n_atoms
+    A1, A2 = int(n[w["i1"]].max()), int(n[w["i2"]].max())
+    pick = np.random.RandomState(4).choice(B, 6, replace=False)
+
+    def dense(idx, A):
+        atoms = np.zeros((len(idx), A), np.int32); adj = np.zeros((len(idx), 4, A, A), np.float32)
+        for b, k in enumerate(idx):
+            m = w["store"][k]
+            atoms[b, :m.n] = m.atoms; adj[b, :, :m.n, :m.n] = m.dense_adj()
+        return torch.from_numpy(atoms), torch.from_numpy(adj)
+
+    a1, j1 = dense(w["i1"][pick], A1)
+    a2, j2 = dense(w["i2"][pick], A2)
+    p64 = {k: v.double() for k, v in w["p"].items()}
+    yo, g1o, g2o = O.pair_forward(p64, a1, j1.double(), a2, j2.double(), n_layers=4, attn="nie")
+    sel = torch.from_numpy(pick).to(y.device)
+    close(y[sel], yo, "predict logits"); close(g1[sel], g1o, "predict g1"); close(g2[sel], g2o, "predict g2")

@@ -10,8 +10,8 @@ row classes of the pair kernels and the largest molecule of each side.
 
 C2: GGNN 4-step d=128 tied + Nie (models/ggnn.py:584-654, nie_coattention.py:335-396);  C3: RelGCN 3x128 + Nie
 (models/relgcn.py:61-73);  C4: GGNN d=256 + MLP(37), multi-hot labels, the unfused planned operators
-(train_ggnn_hole_multi_class_x37.py:71-91).  Tolerance: 1e-4 of the tensor's max-abs (north star); the achieved error is
-printed and logged (tests/parity_util.py).  Parity unpinned: the oracle is a restatement, SURVEY.md 8(c)."""
+(train_ggnn_hole_multi_class_x37.py:71-91).  Tolerance: 2e-5 of the tensor's max-abs (the north star asks 1e-4; achieved: 6e-7 .. 4e-6);
+the achieved error is printed and logged (tests/parity_util.py).  Parity unpinned: the oracle is a restatement, SURVEY.md 8(c)."""
 import numpy as np
 import pytest
 import torch
@@ -21,6 +21,7 @@ from parity_util import close
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 B = 1024
+TOL = 2e-5          # achieved in round 3: 1.4e-6 (C2), 4.1e-6 (C3), 6.2e-7 (C4) -- five times tighter than the north star's 1e-4
 
 
 def _pick_pairs(n1, n2, k=8):
@@ -110,12 +111,13 @@ def _run(config):
         loss.backward()
         opt.collect_grads()
         torch.cuda.synchronize()
-        close(y[T(pick).to(dev)], yo, f"{config} logits of the live pairs (rep {rep})")
-        close(loss, lo, f"{config} loss (rep {rep})")
+        close(y[T(pick).to(dev)], yo, f"{config} logits of the live pairs (rep {rep})", tol=TOL)
+        close(loss, lo, f"{config} loss (rep {rep})", tol=TOL)
         off, worst = 0, 0.0
         for name, shp in zip(opt.names, opt.shapes):
             n = int(np.prod(shp))
-            worst = max(worst, close(opt.grad[off:off + n].view(shp), go[name.replace(".", "/")], f"{config} grad {name} (rep {rep})"))
+            worst = max(worst, close(opt.grad[off:off + n].view(shp), go[name.replace(".", "/")], f"{config} grad {name} (rep {rep})",
+                                     tol=TOL))
             off += n
     assert pb.n_tiles > 256 and len(pick) >= 8
     return worst
