@@ -197,9 +197,9 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if os.environ.get("BMP_BENCH_RANK_CHECK_ONLY") == "1":        # tests/test_bench_launch.py: the launch path without a GPU
-        print(json.dumps({"rank_check": True, "rank": rank, "local_rank": local_rank, "world": world,
-                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
-        return
+        os.write(1, (json.dumps({"rank_check": True, "rank": rank, "local_rank": local_rank, "world": world,
+                                 "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}) + "\n").encode())
+        return                  # (one write per rank: the ranks share the launcher's stdout)
     _heavy_imports()
     # rehearsal switches for a one-GPU box (never set by the driver): all ranks on device 0, collectives over gloo
     one_device = os.environ.get("BMP_BENCH_ONE_DEVICE") == "1"
@@ -224,8 +224,9 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from bmp import synth, packed, _lib
+    from bmp import synth, packed, _lib, enclayout
     from bmp.predictor import build_pair_predictor
+    LAYOUT = os.environ.get("BMP_BENCH_LAYOUT", "encoder")
     from bmp.dp import FlatAdam
     L = _lib.lib()
 
@@ -271,11 +272,13 @@ def main():
             self.steps_per_epoch = len(self.idx1) // self.gb
             nb = self.steps_per_epoch if n_batches is None else min(n_batches, self.steps_per_epoch)
             self.batches = [self.collate(self.idx1, self.idx2, self.label, k) for k in range(nb)]      # resident
-            n_atoms = sum(pb.n_real_atoms for pb, _ in self.batches)
-            self.n_rows = sum(pb.n_rows for pb, _ in self.batches)
+            inst = [getattr(b_, "pb", b_) for b_, _ in self.batches]               # the per-instance batches (real atoms, bonds)
+            encs = [getattr(b_, "pb_enc", b_) for b_, _ in self.batches]           # what the encoder's kernels walk
+            n_atoms = sum(pb.n_real_atoms for pb in inst)
+            self.n_rows = sum(pb.n_rows for pb in encs)
             self.n_atoms = n_atoms
             self.atoms_per_pair = n_atoms / (len(self.batches) * PAIRS_PER_GPU)
-            self.edges_per_pair = sum(pb.n_edges for pb, _ in self.batches) / (len(self.batches) * PAIRS_PER_GPU)
+            self.edges_per_pair = sum(pb.n_edges for pb in inst) / (len(self.batches) * PAIRS_PER_GPU)
             torch.manual_seed(777)
             self.model = build_pair_predictor(hidden_dim=c["d"], out_dim=c["o"], n_layers=c["layers"], attn=c["attn"], head=HEAD,
                                               encoder=c["encoder"], class_num=c["class_num"]).to(dev)
@@ -286,10 +289,15 @@ def main():
             self.alg_f = algorithmic_flops_per_pair(c, self.atoms_per_pair)
             self.alg_b = algorithmic_bytes_per_pair(c, self.atoms_per_pair, self.edges_per_pair)
 
-        def collate(self, i1, i2, lab, k, B=PAIRS_PER_GPU, gbatch=None):
-            """Global batch k of the pair list (i1, i2, lab): this rank's shard, packed on the device."""
+        def collate(self, i1, i2, lab, k, B=PAIRS_PER_GPU, gbatch=None, dedup=False):
+            """Global batch k of the pair list (i1, i2, lab): this rank's shard, packed on the device -- the per-instance
+            batch and, for the encoder, the encoder layout (bmp/enclayout.py: real atoms + one pad row per tile, tile heights
+            balanced over the CUs; every molecule INSTANCE encoded unless ``dedup``).  BMP_BENCH_LAYOUT=instance: the
+            per-instance batch alone (round 2's form)."""
             lo = k * (gbatch or B * world) + rank * B
-            return packed.pack_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B])
+            if LAYOUT == "instance" and not dedup:
+                return packed.pack_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B])
+            return enclayout.encode_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B], dedup=dedup)
 
         def train_step(self, pb, t, collective=True):
             opt = self.opt
@@ -338,8 +346,10 @@ def main():
             nk = L.bmp_prof_collect(key, cnt, ms_, fl, by, cap)
             if plan is not None:
                 plan.side, plan.split = side_saved, split_saved
-            rows_prof = sum(self.batches[i % len(self.batches)][0].n_rows for i in range(n_prof))
-            real_frac = sum(self.batches[i % len(self.batches)][0].n_real_atoms for i in range(n_prof)) / rows_prof
+            enc_of = lambda b_: getattr(b_, "pb_enc", b_)
+            rows_prof = sum(enc_of(self.batches[i % len(self.batches)][0]).n_rows for i in range(n_prof))
+            real_frac = sum(getattr(self.batches[i % len(self.batches)][0], "pb", self.batches[i % len(self.batches)][0]).n_real_atoms
+                            for i in range(n_prof)) / rows_prof
             kern = {key[i]: dict(launches=cnt[i] / n_prof, ms=ms_[i] / n_prof, flops=fl[i] / n_prof) for i in range(nk)}
             if not kern:
                 return None
@@ -458,22 +468,17 @@ def main():
     # ---- de-duplication leg (SURVEY.md 8(d) caveat: reported BESIDE the per-instance figure, never instead of it) ----
     dedup = None
     if not args.no_extras and world == 1 and cfg["attn"]:
-        from bmp.dedup import dedup_from_store_device
         nd, n_d = min(24, steps_per_epoch), 40
-        dds = []
-        for k in range(nd):
-            lo = k * gb
-            dds.append(dedup_from_store_device(dstore, [idx1[lo:lo + PAIRS_PER_GPU], idx2[lo:lo + PAIRS_PER_GPU]],
-                                               labels=label[lo:lo + PAIRS_PER_GPU]))
+        dds = [env.collate(idx1, idx2, label, k, dedup=True) for k in range(nd)]
         for i in range(4):
             env.train_step(*dds[i % nd])
         dt_d, _ = timed(n_d, lambda i: env.train_step(*dds[(4 + i) % nd]))
         v_d = gb * n_d / dt_d
         dedup = dict(value=round(v_d, 1), unit="pairs/s", steps=n_d, ms_per_step=round(1e3 * dt_d / n_d, 3),
-                     distinct_per_step=round(float(np.mean([d_.n_distinct for d_, _ in dds])), 1), instances_per_step=2 * PAIRS_PER_GPU,
-                     rows_encoded_per_step=round(float(np.mean([d_.pb_u.n_rows for d_, _ in dds]))),
+                     distinct_per_step=round(float(np.mean([d_.n_encoded for d_, _ in dds])), 1), instances_per_step=2 * PAIRS_PER_GPU,
+                     rows_encoded_per_step=round(float(np.mean([d_.pb_enc.n_rows for d_, _ in dds]))),
                      speedup=round(v_d / value, 3),
-                     what="every DISTINCT molecule of a step encoded once (bmp/dedup.py), co-attention, MLP, loss, backward and Adam as "
+                     what="every DISTINCT molecule of a step encoded once (bmp/enclayout.py, dedup=True), co-attention, MLP, loss, backward and Adam as "
                           "in `value`; same pairs, same result up to float32 summation order.  `value`, `roofline` and `whole_step` "
                           "are per-instance figures and do not include this")
         del dds
@@ -514,6 +519,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"] + f", {PAIRS_PER_GPU} pairs/GPU/step, every molecule instance encoded; the "
                                    f"{steps_per_epoch} batches of one epoch resident in HBM, cycled",
+                       "layout": ("encoder layout: real atoms + one pad row per tile, tiles of 1..4 live 32-row blocks balanced over "
+                                  "the 256 CUs (bmp/enclayout.py); readout and co-attention on the per-instance rows")
+                       if LAYOUT != "instance" else "per-instance packed layout, whole 128-row tiles",
                        "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": gb, "parallelism": f"dp{world}",
                        "atoms_per_pair": round(atoms_per_pair_main, 2), "real_row_fraction": round(real_row_fraction_main, 4),
                        "loss": round(loss_val, 5)},

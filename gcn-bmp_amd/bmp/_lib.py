@@ -38,15 +38,15 @@ SIGNATURES = {
     "bmp_gru_state_bwd_ws_floats": (_Z, [_I, _I]),
     "bmp_gru_state_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11 + [_Z, _P]),
     "bmp_ggnn_step_supported": (_I, [_I]),
-    "bmp_ggnn_step_fwd": (_I, [_P, _I, _I, _I, _I] + [_P] * 13),
-    "bmp_ggnn_step_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I] + [_P] * 9),
+    "bmp_ggnn_step_fwd": (_I, [_P, _I, _I, _I, _I] + [_P] * 15),
+    "bmp_ggnn_step_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I] + [_P] * 11),
     "bmp_ggnn_step_wgrad_ws_floats": (_Z, [_I, _I]),
     "bmp_ggnn_step_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "bmp_readout_tile_supported": (_I, [_I, _I, _I]),
     "bmp_readout_tile_fwd": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "bmp_relgcn_layer_supported": (_I, [_I, _I]),
-    "bmp_relgcn_layer_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "bmp_relgcn_layer_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "bmp_relgcn_layer_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "bmp_relgcn_layer_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "bmp_relgcn_layer_wgrad_ws_floats": (_Z, [_I, _I]),
     "bmp_relgcn_layer_wgrad": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "bmp_readout_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P]),
@@ -69,13 +69,14 @@ SIGNATURES = {
     "bmp_dense_to_csr": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _P]),
     "bmp_collate_plan": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P]),
     "bmp_collate_pair_meta": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
-    "bmp_collate_emit": (_I, [_P, _I] + [_P] * 16 + [_P]),
+    "bmp_collate_emit": (_I, [_P, _I] + [_P] * 16 + [_P, _P]),
+    "bmp_collate_plan_enc": (_I, [_P, _P, _I, _P, _I, _I, _I, _I] + [_P] * 11),
     "bmp_bimpm_supported": (_I, [_I, _I, _I]),
     "bmp_bimpm_ws_floats": (_Z, [_I, _I, _I, _I, _I]),
     "bmp_bimpm_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "bmp_bimpm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    "bmp_molrows_expand": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "bmp_molrows_reduce": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "bmp_encrows_expand": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "bmp_encrows_reduce": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "bmp_rescale_adj": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),

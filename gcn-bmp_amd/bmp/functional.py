@@ -238,9 +238,9 @@ class GGNNStepFn(Function):
         UcTp = _cached(cache, ("f", UcT.data_ptr()), lambda: pack_k4(UcT))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
-        check(L.bmp_ggnn_step_fwd(ptr(h), 0, pb.n_tiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+        check(L.bmp_ggnn_step_fwd(ptr(h), 0, pb.n_mtiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                   ptr(WTp), ptr(bE), ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout),
-                                  stream()), "bmp_ggnn_step_fwd")
+                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), stream()), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, WT, AT, UcT, m, rz, c)
         ctx.pb, ctx.first, ctx.cache = pb, int(first), cache
         if cache is not None:       # how many steps of this call share both weight sets (see backward)
@@ -261,9 +261,9 @@ class GGNNStepFn(Function):
         Uc = _cached(cache, ("b", UcT.data_ptr()), lambda: pack_k4(UcT.t()))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         dh, gda = f(N, d), f(N, 7 * d)
-        check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
+        check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(A), ptr(Uc), ptr(dh), ptr(gda),
-                                  stream()), "bmp_ggnn_step_bwd")
+                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), stream()), "bmp_ggnn_step_bwd")
         # Steps that share BOTH weight sets (tied layers) accumulate their weight gradients in one set of
         # buffers inside the kernels; only the last of them to run hands the sums to autograd.
         grp = ("g", WT.data_ptr(), AT.data_ptr())
@@ -466,8 +466,10 @@ def _fwd_parts(state, pb, keep=()):
     ``torch.no_grad()`` nothing else holds them once the Function returns: the plan's state keeps them until the join, so the
     caching allocator cannot hand their blocks to a later main-stream launch while the part stream still uses them."""
     sp = state.get("split") if state is not None else None
-    T = pb.n_tiles
-    if sp is None or T < 64:
+    T = pb.n_mtiles
+    # (the encoder layout's tile table lists the tallest tiles first: ONE launch in that order lets every CU that finishes
+    #  a short tile pick up the next one; two chains would dispatch in an order nobody controls)
+    if sp is None or T < 64 or (pb.mt_row0 is not None and not _ENC_SPLIT):
         return ((0, T, stream()),)
     T0 = pb.side_tiles[1] if (len(pb.side_tiles) == 3 and 0 < pb.side_tiles[1] < T) else T // 2
     cur = torch.cuda.current_stream()
@@ -494,7 +496,7 @@ def fork_parts(state, pb) -> bool:
     packet between two hardware queues (tens of microseconds) and, placed before every step, it ties chain B's step t to
     chain A's step t-1 (rocprofv3 kernel trace).  Returns whether the chains are open."""
     sp = state.get("split") if state is not None else None
-    if sp is None or pb.n_tiles < 64 or not _FORK_ONCE:
+    if sp is None or pb.n_mtiles < 64 or not _FORK_ONCE or (pb.mt_row0 is not None and not _ENC_SPLIT):
         return False
     cur = torch.cuda.current_stream()
     sp.stream.wait_stream(cur)
@@ -514,6 +516,7 @@ def _join_parts(state) -> None:
 
 
 _FORK_ONCE = os.environ.get("BMP_FWD_FORK_ONCE", "1") != "0"          # A/B switch of fork_parts
+_ENC_SPLIT = os.environ.get("BMP_ENC_SPLIT", "0") == "1"             # A/B: two chains also over an encoder-layout tile table
 _RO_DEFER = os.environ.get("BMP_READOUT_DEFER", "1") != "0"
 _RO_OFF_CHAIN = os.environ.get("BMP_READOUT_OFF_CHAIN", "1") != "0"        # A/B switch of PReadoutFn's off_chain form
 
@@ -596,7 +599,7 @@ class PStepFn(Function):
         for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                       ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
-                                      ptr(c), ptr(hout), st), "bmp_ggnn_step_fwd")
+                                      ptr(c), ptr(hout), ptr(pb.mt_row0), ptr(pb.mt_nblk), st), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
         _register(state, gkey)
@@ -611,9 +614,9 @@ class PStepFn(Function):
         dhout = dhout.contiguous()
         dh = torch.empty(N, d, dtype=torch.float32, device=h.device)
         gda = torch.empty(N, 7 * d, dtype=torch.float32, device=h.device)
-        check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_tiles, d, first, ptr(pb.csrT_ptr),
+        check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
-                                  ptr(dh), ptr(gda), stream()), "bmp_ggnn_step_bwd")
+                                  ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), stream()), "bmp_ggnn_step_bwd")
         acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
 
         def wgrad(st, ws_of):
@@ -708,7 +711,8 @@ class PGRUFn(Function):
         f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=h.device)
         rz, c, hout = f(N, 2 * d), f(N, d), f(N, d)
         R = pb.R
-        for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):          # row-wise: a tile range is a pointer offset
+        parts = _fwd_parts(state, pb, (h, m, rz, c, hout)) if pb.mt_row0 is None else ((0, pb.n_tiles, stream()),)
+        for t0, nt, st in parts:          # row-wise: a tile range is a pointer offset
             r0 = t0 * R
             check(L.bmp_gru_fwd(_at(h, r0), _at(m, r0), nt, d, int(first), ptr(W["AT"]), ptr(W["UcT"]), ptr(W["b"]), _at(rz, r0),
                                 _at(c, r0), _at(hout, r0), st), "bmp_gru_fwd")
@@ -748,7 +752,8 @@ class PMsgFn(Function):
         agg, wdeg, out = f(N, 4 * d_in), f(N, 4), f(N, d_out)
         # Without a self connection x is only the gather's source, addressed by the absolute row numbers of the CSR: a tile
         # range is then an offset into the row pointers and the outputs (the entries they index stay where they are).
-        parts = _fwd_parts(state, pb, (x, agg, wdeg, out)) if W.get("WsT") is None else ((0, pb.n_tiles, stream()),)
+        parts = (_fwd_parts(state, pb, (x, agg, wdeg, out)) if (W.get("WsT") is None and pb.mt_row0 is None)
+                 else ((0, pb.n_tiles, stream()),))
         R = pb.R
         for t0, nt, st in parts:
             r0 = t0 * R
@@ -795,7 +800,8 @@ def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None, bufs=None):
     out, wdeg = bufs if bufs is not None else rel_buffers(N, d, x.device)
     for t0, nt, st in _fwd_parts(state, pb, (x, out, wdeg)):
         check(L.bmp_relgcn_layer_fwd(ptr(x), t0, nt, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
-                                     ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), st), "bmp_relgcn_layer_fwd")
+                                     ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), ptr(pb.mt_row0), ptr(pb.mt_nblk), st),
+              "bmp_relgcn_layer_fwd")
     return out, wdeg
 
 
@@ -804,8 +810,9 @@ def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate,
     N, d = x.shape
     dx = torch.empty(N, d, dtype=torch.float32, device=x.device)
     gda = torch.empty(N, 5 * d, dtype=torch.float32, device=x.device)
-    check(L.bmp_relgcn_layer_bwd(ptr(dout), ptr(out), act, pb.n_tiles, d, ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val),
-                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), stream()), "bmp_relgcn_layer_bwd")
+    check(L.bmp_relgcn_layer_bwd(ptr(dout), ptr(out), act, pb.n_mtiles, d, ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val),
+                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), stream()),
+              "bmp_relgcn_layer_bwd")
 
     def wgrad(st, ws_of):
         nws = L.bmp_relgcn_layer_wgrad_ws_floats(N, d)

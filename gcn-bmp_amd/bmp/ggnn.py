@@ -361,6 +361,23 @@ class GGNN(nn.Module):
     def _forward_fast(self, pb, fast, h_in=None):
         """The encoder on the plan's prepared weights: embed, fused steps, readout -- no layout work, no weight
         gradients through autograd."""
+        h, h0 = self._encode_fast(pb, fast, h_in)
+        self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
+        return self._readout_fast(h, h0, pb, fast)
+
+    def _readout_fast(self, h, h0, pb, fast):
+        P, G, state, _tape = fast
+        infer = not torch.is_grad_enabled()
+        if not self._plan_fused():
+            return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
+                                       dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
+                                       getattr(self, "_readout_off_chain", False))
+        return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
+                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
+                                   getattr(self, "_readout_off_chain", False), infer)
+
+    def _encode_fast(self, pb, fast, h_in=None):
+        """embed + propagation steps on the plan's prepared weights: (h after the last step, h0)."""
         P, G, state, tape = fast
         if h_in is None:
             pb.check_atom_ids(P["embed.W"].shape[0])
@@ -376,10 +393,7 @@ class GGNN(nn.Module):
                 Gg = dict(dAT=G[f"gru_{mode}.dAT"], dUcT=G[f"gru_{mode}.dUcT"], db=G[f"gru_{mode}.db"])
                 h = Fn.PGRUFn.apply(h, m, pb, Wg, Gg, state, f"gru_{mode}", step == 0)
             Fn._join_parts(state)             # the steps ran as two chains of tiles
-            self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
-            return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"]),
-                                       dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
-                                       getattr(self, "_readout_off_chain", False))
+            return h, h0
         # every step's outputs first, then the two chains of tiles are opened ONCE (Fn.fork_parts) and run to the join
         # without another cross-stream wait
         infer = not torch.is_grad_enabled()      # predict under no-backprop: nothing is kept for a backward
@@ -392,10 +406,46 @@ class GGNN(nn.Module):
             Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
             h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0, bufs[step])
         Fn._join_parts(state)                 # the steps ran as two chains of tiles: whole arrays are read from here on
-        self.atoms = PackedAtoms(h, pb, 0 if pb.dense_map is not None else None)
-        return Fn.PReadoutFn.apply(h, h0, pb, dict(WT=P["ro.WT"], b=P["ro.b"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")),
-                                   dict(dWT=G["ro.dWT"], db=G["ro.db"]), Fn.ACT["identity"], state,
-                                   getattr(self, "_readout_off_chain", False), infer)
+        return h, h0
+
+    def encode_rows(self, pb: PackedMolBatch):
+        """embed + the propagation steps (models/ggnn.py:599-627) WITHOUT the readout: (h, h0) on the rows of ``pb`` -- the
+        entry the pair predictor uses for a batch in the encoder layout (bmp/enclayout.py), whose readout runs on the
+        per-instance rows (``readout_rows``)."""
+        if self.concat_hidden or (self.dropout_rate != 0.0 and self.training):
+            raise NotImplementedError("encode_rows: concat_hidden / training dropout take the per-instance batch form")
+        fast = getattr(self, "_fast", None)
+        if fast is not None and not pb.oversized:
+            return self._encode_fast(pb, fast)
+        pb.check_atom_ids(self.embed.W.shape[0])
+        h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
+        h0 = h
+        fused = self.fused and Fn.step_supported(self.hidden_dim) and not pb.oversized
+        later, msgw, cache = None, {}, {}
+        for step in range(self.n_layers):
+            li = 0 if self.weight_tying else step
+            if li not in msgw:
+                msgw[li] = message_kernel_weights(self.message_layers[li])
+            WT, bE = msgw[li]
+            if step == 0:
+                AT, UcT, b = self.update_layer.kernel_weights(first=True)
+            else:
+                if later is None:
+                    later = self.update_layer.kernel_weights(first=False)
+                AT, UcT, b = later
+            if fused:
+                h = Fn.GGNNStepFn.apply(h, WT, bE, AT, UcT, b, pb, step == 0, cache)
+            else:
+                m = Fn.MsgFn.apply(h, WT, bE, None, None, pb, Fn.ACT["identity"])
+                h = Fn.GRUFn.apply(h, m, AT, UcT, b, pb, step == 0)
+        return h, h0
+
+    def readout_rows(self, h, h0, pb: PackedMolBatch):
+        """The gated-sum readout (models/ggnn.py:333-341) of row tensors that live on ``pb``'s rows."""
+        fast = getattr(self, "_fast", None)
+        if fast is not None and not pb.oversized:
+            return self._readout_fast(h, h0, pb, fast)
+        return self.readout(h, h0, pb, 0)
 
     def forward(self, atom_array, adj=None):
         """models/ggnn.py:584-654.  ``atom_array`` is the dense int32 (mb, A) array with ``adj``

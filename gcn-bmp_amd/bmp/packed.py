@@ -143,7 +143,16 @@ class PackedMolBatch:
     mol_nrows_host: Optional[np.ndarray] = None   # host copy of mol_nrows (pair metadata without a device sync)
     row_mol: Optional[torch.Tensor] = None        # (N,) molecule of every row, -1 for rows of no molecule
     atom_id_range: Tuple[int, int] = (0, 0)       # (min, max) atom id of the batch, known on the host at pack time
+    # The encoder layout (bmp/enclayout.py): molecule tiles of 1..4 live 32-row blocks over dense rows -- tile t = rows
+    # [mt_row0[t], mt_row0[t] + 32 * mt_nblk[t]).  None: tile t = rows [R t, R t + R) and n_mtiles == n_tiles.
+    mt_row0: Optional[torch.Tensor] = None
+    mt_nblk: Optional[torch.Tensor] = None
+    n_mtiles: int = -1
     _cache: dict = field(default_factory=dict, repr=False)
+
+    def __post_init__(self):
+        if self.n_mtiles < 0:
+            self.n_mtiles = self.n_tiles
 
     @property
     def n_rows(self) -> int:
@@ -535,6 +544,10 @@ class DeviceMolStore:
             ev = self._events[self._cur] = torch.cuda.Event()
         ev.record()
 
+    def _staged_unused(self) -> None:
+        """The buffer handed out by ``_staging`` was not sent after all: it is free again at once."""
+        self._k = self._cur
+
 
 def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], R: int = DEFAULT_R,
                            pad_to: Optional[Sequence[int]] = None, labels: Optional[np.ndarray] = None):
@@ -590,7 +603,7 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
     d = dstore.dev
     check(L.bmp_collate_emit(ptr(up), I, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(d[5]), ptr(d[6]),
                              ptr(atom_id), ptr(row_w), ptr(row_mol), ptr(csr_ptr), ptr(csr_col), ptr(csr_val), ptr(csrT_ptr),
-                             ptr(csrT_col), ptr(csrT_val), _c_void_p(cs.cuda_stream)), "bmp_collate_emit")
+                             ptr(csrT_col), ptr(csrT_val), None, _c_void_p(cs.cuda_stream)), "bmp_collate_emit")
     if cs is not cur:
         for t in (up, ibuf, fbuf):          # allocated on the collate stream, read by the caller's: no reuse before that work
             t.record_stream(cur)

@@ -36,17 +36,20 @@ class GraphConvPredictorForPair(nn.Module):
     def _encode(self, atoms_1, adjs_1, atoms_2, adjs_2):
         """Siamese encoder (train_binary.py:91-94).  A two-sided PackedMolBatch in the first slot
         encodes both sides in ONE pass (same weights, so it is the same computation)."""
-        from .dedup import DedupPairBatch, MolRowsFn
-        if isinstance(atoms_1, DedupPairBatch):
-            # every DISTINCT molecule of the batch encoded once (bmp/dedup.py; SURVEY.md 8(d)); the co-attention works on the
-            # per-instance rows.  Only with a co-attention that does not read the molecule vectors (the fine family).
-            if not getattr(self.attn, "ignores_graph_vectors", False):
-                raise NotImplementedError("the de-duplicated batch form needs a co-attention of the fine family (Nie / VQA / Pooling)")
-            dd = atoms_1
-            self.graph_conv(dd.pb_u)                          # (its readout output is not used: nie_coattention.py:335-370)
-            rows = MolRowsFn.apply(self.graph_conv.get_atom_array().rows, dd)
-            at = PackedAtoms(rows, dd.pb, None)
-            return None, None, at, at, (0, dd.pb.side_mols[1])
+        from .enclayout import EncBatch, EncRowsFn
+        if isinstance(atoms_1, EncBatch):
+            # the batch in the encoder layout (bmp/enclayout.py: real atoms + one pad row per tile, tile heights balanced over
+            # the CUs; optionally every distinct molecule once): the encoder runs there, readout and co-attention on the
+            # per-instance rows copied from it
+            eb = atoms_1
+            h, h0 = self.graph_conv.encode_rows(eb.pb_enc)
+            rows = EncRowsFn.apply(h, eb)
+            rows0 = None if h0 is None else EncRowsFn.apply(h0, eb)
+            at = PackedAtoms(rows, eb.pb, None)
+            self.graph_conv.atoms = at
+            g = self.graph_conv.readout_rows(rows, rows0, eb.pb)
+            B = eb.pb.side_mols[1]
+            return g[:B], g[B:], at, at, (0, B)
         if isinstance(atoms_1, PackedMolBatch) and len(atoms_1.side_mols) == 3 and atoms_2 is None:
             pb = atoms_1
             g = self.graph_conv(pb)

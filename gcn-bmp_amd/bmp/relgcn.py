@@ -197,6 +197,37 @@ class RelGCN(nn.Module):
         return out
 
     def _forward_fast(self, pb, fast):
+        x, _ = self._encode_fast(pb, fast)
+        self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
+        return self._readout_fast(x, pb, fast)
+
+    def _readout_fast(self, x, pb, fast):
+        P, G, state, _tape = fast
+        return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")), dict(dWT=G["ro.dWT"]),
+                                   Fn.ACT["tanh"], state, getattr(self, "_readout_off_chain", False), not torch.is_grad_enabled())
+
+    def encode_rows(self, pb):
+        """embed + the layers (models/relgcn.py:67-71) WITHOUT the readout: (x, None) on the rows of ``pb`` (the entry the pair
+        predictor uses for a batch in the encoder layout, bmp/enclayout.py)."""
+        if self.input_type != 'int':
+            raise NotImplementedError("encode_rows needs integer atom ids")
+        fast = getattr(self, "_fast", None)
+        if fast is not None and not pb.oversized:
+            return self._encode_fast(pb, fast)
+        pb.check_atom_ids(self.embed.W.shape[0])
+        x = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
+        pbs = rescale_adj(pb) if self.scale_adj else pb
+        for conv in self.rgcn_convs:
+            x = conv(x, pbs, act="tanh")
+        return x, None
+
+    def readout_rows(self, x, h0, pb):
+        fast = getattr(self, "_fast", None)
+        if fast is not None and not pb.oversized:
+            return self._readout_fast(x, pb, fast)
+        return self.rgcn_readout(x, pb)
+
+    def _encode_fast(self, pb, fast):
         P, G, state, tape = fast
         pb.check_atom_ids(P["embed.W"].shape[0])
         x = Fn.PEmbedFn.apply(tape, P["embed.W"], pb.atom_id, G["embed.dW"], state)
@@ -218,9 +249,7 @@ class RelGCN(nn.Module):
             Fn._join_parts(state)             # an unfused layer reads whole arrays
             x = Fn.PMsgFn.apply(x, pbs, W, Gl, state, f"c{l}", Fn.ACT["tanh"])
         Fn._join_parts(state)                 # fused layers ran as two chains of tiles
-        self.atoms = PackedAtoms(x, pb, 0 if pb.dense_map is not None else None)
-        return Fn.PReadoutFn.apply(x, None, pb, dict(WT=P["ro.WT"], Wnat=P["ro.Wnat"], WTp=P.get("ro.WTp")), dict(dWT=G["ro.dWT"]),
-                                   Fn.ACT["tanh"], state, getattr(self, "_readout_off_chain", False), not torch.is_grad_enabled())
+        return x, None
 
     def forward(self, h, adj=None):
         """models/relgcn.py:61-73."""

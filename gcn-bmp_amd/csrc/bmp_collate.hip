@@ -130,6 +130,150 @@ extern "C" int bmp_collate_plan(const int* st_nrows, const int* st_nedges, int n
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The ENCODER LAYOUT of a batch (csrc/bmp_enc.hip): the real atoms of every encoded molecule, one pad row per tile, tiles of
+// 1..4 live 32-row blocks, dense rows.  HOST function, size arithmetic only.
+//
+// Encoded molecules: every instance of `mids` (dedup == 0), or the DISTINCT molecules in ascending store order
+// (dedup != 0: SURVEY.md 8(d) caveat).  Tile heights: the batch needs about sum(n) / 32 block-rounds of one CU; with
+// b = that number per CU of the n_cu CUs (b <= 7), every CU is meant to get the heights DEC[b] (7 -> 4 + 3, 6 -> 3 + 3,
+// 5 -> 3 + 2, else b itself): the bin list is n_cu bins of every height of DEC[b], tall first, followed by spare bins (as
+// tall as their first molecule needs; 128 rows when b = 8, the uniform fallback); molecules go first-fit in stable
+// decreasing-size order (a bin of height h holds 32 h - 1 atoms: one row stays for the pad row).  Tiles = the non-empty spare bins (they took what fitted nowhere else: the largest molecules), then the
+// non-empty listed bins, in that order -- so the tallest tiles are dispatched first and a CU that finishes a short tile
+// picks up the next one; a tile's height is what its molecules need, ceil((atoms + 1) / 32).  One-block dummy tiles pad the
+// row count to a multiple of 128 (the row-wise kernels' granularity).  Mirrored by bmp.enclayout.plan_enc_numpy (tests).
+//
+// Outputs (all int32; U <= I encoded molecules, T <= U + 3 tiles):
+//   tab [6 * I]   as bmp_collate_plan for the U encoded molecules (row0 | n | mid | ebase | 1 | ndead), stride U
+//   tile_last [I] tile of a molecule that is the last of its tile, else -1 (bmp_collate_emit marks the pad row with it)
+//   uid [I], uptr [I + 1], uinst [I]   encoded molecule of every instance; instances per encoded molecule, ascending
+//   enc_pad [I]   pad row of every encoded molecule's tile
+//   tptr [I + 4], tmols [I]            encoded molecules per tile, ascending
+//   mt_row0 [I + 4], mt_nblk [I + 4]   the tile table
+//   totals [6]: U, T, N_enc, n_edges, n_real (rows of encoded molecules), budget b (8: uniform 128-row bins)
+// Returns -2000 if a molecule has more than R - 1 atoms (the caller keeps the per-instance layout for such a batch).
+extern "C" int bmp_collate_plan_enc(const int* st_nrows, const int* st_nedges, int n_store, const int* mids, int I, int dedup,
+                                    int n_cu, int R, int* tab, int* tile_last, int* uid, int* uptr, int* uinst, int* enc_pad,
+                                    int* tptr, int* tmols, int* mt_row0, int* mt_nblk, long long* totals) {
+    BMP_REQUIRE(st_nrows && st_nedges && mids && tab && tile_last && uid && uptr && uinst && enc_pad && tptr && tmols && mt_row0 &&
+                mt_nblk && totals && I >= 1 && n_cu >= 1 && R == 128);
+    // ---- encoded molecules ----
+    std::vector<int> umid;
+    if (dedup) {
+        std::vector<int> seen(n_store, -1);
+        for (int i = 0; i < I; ++i) { BMP_REQUIRE(mids[i] >= 0 && mids[i] < n_store); seen[mids[i]] = 0; }
+        for (int m = 0; m < n_store; ++m) if (seen[m] == 0) { seen[m] = (int)umid.size(); umid.push_back(m); }
+        for (int i = 0; i < I; ++i) uid[i] = seen[mids[i]];
+    } else {
+        umid.assign(mids, mids + I);
+        for (int i = 0; i < I; ++i) { BMP_REQUIRE(mids[i] >= 0 && mids[i] < n_store); uid[i] = i; }
+    }
+    const int U = (int)umid.size();
+    int* row0 = tab; int* nn = tab + U; int* mid = tab + 2 * (size_t)U; int* ebase = tab + 3 * (size_t)U;
+    int* padw = tab + 4 * (size_t)U; int* ndead = tab + 5 * (size_t)U;
+    long long tot = 0, n_edges = 0;
+    for (int u = 0; u < U; ++u) {
+        mid[u] = umid[u];
+        nn[u] = st_nrows[umid[u]] - 1;
+        if (nn[u] + 1 > R) return -2000;
+        BMP_REQUIRE(nn[u] >= 1);
+        tot += nn[u]; n_edges += st_nedges[umid[u]];
+        padw[u] = 1; ndead[u] = 0; tile_last[u] = -1;
+    }
+    for (int i = U; i < I; ++i) tile_last[i] = -1;
+    {   // instances per encoded molecule (counting sort, stable)
+        for (int u = 0; u <= U; ++u) uptr[u] = 0;
+        for (int i = 0; i < I; ++i) ++uptr[uid[i] + 1];
+        for (int u = 0; u < U; ++u) uptr[u + 1] += uptr[u];
+        std::vector<int> at(uptr, uptr + U);
+        for (int i = 0; i < I; ++i) uinst[at[uid[i]]++] = i;
+    }
+    // ---- tile heights ----
+    static const int DEC[8][2] = {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}, {3, 2}, {3, 3}, {4, 3}};
+    int b = 8;
+    for (int k = 1; k <= 7; ++k) {
+        long long cap = 0;
+        for (int j = 0; j < 2; ++j) if (DEC[k][j]) cap += (long long)n_cu * (32 * DEC[k][j] - 1);
+        if (100 * tot <= 99 * cap) { b = k; break; }
+    }
+    std::vector<int> caps;
+    if (b < 8)
+        for (int j = 0; j < 2; ++j) if (DEC[b][j]) for (int q = 0; q < n_cu; ++q) caps.push_back(32 * DEC[b][j] - 1);
+    const int n_list = (int)caps.size();
+    for (int q = 0; q < U; ++q) caps.push_back(R - 1);              // spare bins
+    const int NB = (int)caps.size();
+    // leftmost bin with room: max segment tree over the remaining capacities
+    int base = 1;
+    while (base < NB) base <<= 1;
+    std::vector<int> tr(2 * base, -1);
+    for (int q = 0; q < NB; ++q) tr[base + q] = caps[q];
+    for (int q = base - 1; q >= 1; --q) tr[q] = std::max(tr[2 * q], tr[2 * q + 1]);
+    std::vector<int> order(U), cnt(R + 2, 0), bin_of(U), off_in(U), used(NB, 0);
+    for (int u = 0; u < U; ++u) ++cnt[R - nn[u] + 1];
+    for (int k = 1; k <= R + 1; ++k) cnt[k] += cnt[k - 1];
+    for (int u = 0; u < U; ++u) order[cnt[R - nn[u]]++] = u;         // stable, decreasing size
+    for (int q = 0; q < U; ++q) {
+        const int u = order[q], sz = nn[u];
+        int i = 1;
+        BMP_REQUIRE(tr[1] >= sz);
+        while (i < base) i = (tr[2 * i] >= sz) ? 2 * i : 2 * i + 1;
+        const int bn = i - base;
+        bin_of[u] = bn; off_in[u] = used[bn];
+        // a spare bin opened beside the listed ones is only as tall as its first molecule needs (the largest molecules of a
+        // small batch get tiles of their own height instead of filling a few 128-row tiles)
+        if (b < 8 && bn >= n_list && used[bn] == 0) tr[i] = 32 * ((sz + 1 + 31) / 32) - 1;
+        used[bn] += sz; tr[i] -= sz;
+        for (i >>= 1; i >= 1; i >>= 1) tr[i] = std::max(tr[2 * i], tr[2 * i + 1]);
+    }
+    // ---- tiles: non-empty spare bins first, then the non-empty listed bins ----
+    std::vector<int> tile_of_bin(NB, -1);
+    int T = 0, rows = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int lo = pass == 0 ? n_list : 0, hi = pass == 0 ? NB : n_list;
+        for (int q = lo; q < hi; ++q) {
+            if (used[q] == 0) continue;
+            tile_of_bin[q] = T;
+            mt_row0[T] = rows;
+            mt_nblk[T] = (used[q] + 1 + 31) / 32;
+            rows += 32 * mt_nblk[T];
+            ++T;
+        }
+    }
+    const int T_real = T;
+    while (rows % R) { mt_row0[T] = rows; mt_nblk[T] = 1; rows += 32; ++T; }     // dummy tiles (no molecule)
+    // molecules of every tile, ascending; rows; pad rows; dead rows
+    for (int t = 0; t <= T; ++t) tptr[t] = 0;
+    for (int u = 0; u < U; ++u) ++tptr[tile_of_bin[bin_of[u]] + 1];
+    for (int t = 0; t < T; ++t) tptr[t + 1] += tptr[t];
+    {
+        std::vector<int> at(tptr, tptr + T);
+        for (int u = 0; u < U; ++u) tmols[at[tile_of_bin[bin_of[u]]]++] = u;
+    }
+    std::vector<int> last_of_tile(T, -1), last_off(T, -1);
+    for (int u = 0; u < U; ++u) {
+        const int t = tile_of_bin[bin_of[u]];
+        row0[u] = mt_row0[t] + off_in[u];
+        enc_pad[u] = mt_row0[t] + used[bin_of[u]];
+        if (off_in[u] > last_off[t]) { last_off[t] = off_in[u]; last_of_tile[t] = u; }
+    }
+    for (int t = 0; t < T_real; ++t) {
+        const int u = last_of_tile[t];
+        tile_last[u] = t;
+        ndead[u] = mt_row0[t] + 32 * mt_nblk[t] - (row0[u] + nn[u]);
+    }
+    if (T > T_real) ndead[last_of_tile[T_real - 1]] += 32 * (T - T_real);      // the dummy tiles' rows: zero-filled by that molecule
+    // edge bases: encoded molecules in row order
+    std::vector<int> by_row(U);
+    for (int u = 0; u < U; ++u) by_row[u] = u;
+    std::sort(by_row.begin(), by_row.end(), [&](int x, int y) { return row0[x] < row0[y]; });
+    long long e = 0;
+    for (int q = 0; q < U; ++q) { ebase[by_row[q]] = (int)e; e += st_nedges[mid[by_row[q]]]; }
+    BMP_REQUIRE(e == n_edges && e < (1ll << 31));
+    totals[0] = U; totals[1] = T; totals[2] = rows; totals[3] = n_edges; totals[4] = tot; totals[5] = b;
+    return 0;
+}
+
 // Co-attention metadata of a two-sided batch of B pairs (instances [0, B) are side 1, [B, 2B) side 2), from the plan
 // table: what bmp/coattention.py:pair_rows computes with numpy.  meta (8 * B int32 entries, 8-byte aligned):
 //   coff[B] as int64 (= 2B int32) | r1[B] | n1[B] | r2[B] (relative to side 2's first row) | n2[B] |
@@ -181,7 +325,7 @@ __global__ __launch_bounds__(256) void k_collate_emit(const int* __restrict__ ta
                                                       int* __restrict__ atom_id, float* __restrict__ row_w, int* __restrict__ row_mol,
                                                       int* __restrict__ csr_ptr, int* __restrict__ csr_col, float* __restrict__ csr_val,
                                                       int* __restrict__ csrT_ptr, int* __restrict__ csrT_col,
-                                                      float* __restrict__ csrT_val) {
+                                                      float* __restrict__ csrT_val, const int* __restrict__ tile_last) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= I) return;
@@ -200,7 +344,8 @@ __global__ __launch_bounds__(256) void k_collate_emit(const int* __restrict__ ta
         const int r = row0 + nrows + k;
         atom_id[r] = 0;
         row_w[r] = 0.f;
-        row_mol[r] = -1;
+        // encoder layout (bmp_collate_plan_enc): the first row behind a tile's last molecule is the tile's pad row
+        row_mol[r] = (k == 0 && tile_last != nullptr && tile_last[i] >= 0) ? -2 - tile_last[i] : -1;
         csr_ptr[r + 1] = ebase + ne;
         csrT_ptr[r + 1] = ebase + ne;
     }
@@ -214,17 +359,17 @@ __global__ __launch_bounds__(256) void k_collate_emit(const int* __restrict__ ta
     if (row0 == 0 && lane == 0) { csr_ptr[0] = 0; csrT_ptr[0] = 0; }
 }
 
-// tab: the plan table of bmp_collate_plan, on the device.  Output arrays as in bmp/packed.py:PackedMolBatch
+// tab: the plan table of bmp_collate_plan (or bmp_collate_plan_enc, then with its tile_last [I]; else NULL), on the device.  Output arrays as in bmp/packed.py:PackedMolBatch
 // (N = n_tiles * R rows; csr_ptr / csrT_ptr hold N + 1 entries; col / val hold n_edges).
 extern "C" int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, const int* st_eoff, const int* st_atom,
                                 const int* st_rend, const int* st_rendT, const int* st_col, const int* st_colT, int* atom_id,
                                 float* row_w, int* row_mol, int* csr_ptr, int* csr_col, float* csr_val, int* csrT_ptr,
-                                int* csrT_col, float* csrT_val, hipStream_t st) {
+                                int* csrT_col, float* csrT_val, const int* tile_last, hipStream_t st) {
     BMP_REQUIRE(tab && st_rowoff && st_eoff && st_atom && st_rend && st_rendT && st_col && st_colT && atom_id && row_w &&
                 row_mol && csr_ptr && csr_col && csr_val && csrT_ptr && csrT_col && csrT_val && I >= 1);
     hipLaunchKernelGGL(k_collate_emit, dim3((I + 3) / 4), dim3(256), 0, st, tab, I, st_rowoff, st_eoff, st_atom, st_rend,
                        st_rendT, st_col, st_colT, atom_id, row_w, row_mol, csr_ptr, csr_col, csr_val, csrT_ptr, csrT_col,
-                       csrT_val);
+                       csrT_val, tile_last);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -22,6 +22,9 @@ struct StepArgs {
     const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
     int tile0;                      // the launch covers tiles tile0 .. tile0 + gridDim.x - 1 (all arrays whole)
     int first;
+    // optional tile table (nullptr: tile t = rows [128 t, 128 t + 128)): tile t = rows [mt_row0[t], + 32 * mt_nblk[t]),
+    // mt_nblk in 1..4 -- tiles of fewer live 32-row blocks skip the dead blocks' gathers, MFMAs, loads and stores
+    const int* mt_row0; const int* mt_nblk;
     // forward
     const float* h;                 // [N x D] step input
     const float* WT;                // [4D x D]  message weights, K-major (row e*D + k, col c)
@@ -59,9 +62,10 @@ __device__ __forceinline__ void tile_b_prefetch(BPre<NB>& p, const float* const 
     }
 }
 
+// `nrb` (<= RB): live row blocks of this wave (tiles of fewer than four 32-row blocks); the others' A loads and MFMAs are skipped.
 template <int NB, int RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
+                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr, int nrb = RB) {
     // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
     // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
     // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
@@ -78,20 +82,27 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
     }
     f32x4 a0[RB], a1[RB];            // A fragments (LDS) run one k-step ahead
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) a0[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
+    for (int rb = 0; rb < RB; ++rb) a0[rb] = (RB == 1 || rb < nrb) ? *(const f32x4*)(As_wave + rb * 32 * LD + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < K; it += 8) {
         int k2 = k1 + 8; if (k2 >= K) k2 -= K;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b2[nb] = *(const f32x4*)(Bp[nb] + (size_t)k2 * ldw[nb]);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) a1[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k1);
+        for (int rb = 0; rb < RB; ++rb) a1[rb] = (RB == 1 || rb < nrb) ? *(const f32x4*)(As_wave + rb * 32 * LD + k1) : (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
+        if (RB == 1 || nrb == RB) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(a0[rb][t], b0[nb][t], acc[nb][rb]);
+                    for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(a0[rb][t], b0[nb][t], acc[nb][rb]);
+        } else {                         // a short tile: row block 0 only (RB == 2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb][0] = bmp_mfma(a0[0][t], b0[nb][t], acc[nb][0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { b0[nb] = b1[nb]; b1[nb] = b2[nb]; }
@@ -116,7 +127,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 // arrays, or the copy of the tile's entries staged in LDS -- see stage_csr).
 template <int D>
 __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_tile, int LD, const int* ptr, const int* col,
-                                            const float* val, int row0, int e, float* wsum, int* tmask) {
+                                            const float* val, int row0, int e, float* wsum, int* tmask, int nrows = FZ_R) {
     constexpr int F = D / 16;                 // float4 per thread
     const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
     f32x4 acc[F];
@@ -124,6 +135,8 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
     for (int f = 0; f < F; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float wd = 0.f;
     bool any = false;
+    *wsum = 0.f;
+    if (row >= nrows) return false;           // a dead block of a short tile: nothing reads its rows
     const int e0 = ptr[row], e1 = ptr[row + 1];
     for (int ed = e0; ed < e1; ++ed) {
         const int cv = col[ed];
@@ -148,16 +161,16 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
 // microseconds per bond-type pass).  Returns false (and stages nothing) if the tile has more than FZ_ECAP entries.
 #define FZ_ECAP 1024
 __device__ __forceinline__ bool stage_csr(const int* ptr, const int* col, const float* val, int row0, int* rptr, int* ecol,
-                                          float* evalv) {
+                                          float* evalv, int nrows = FZ_R) {
     const int ebase = ptr[row0];
-    const int ne = ptr[row0 + FZ_R] - ebase;
+    const int ne = ptr[row0 + nrows] - ebase;
     if (ne > FZ_ECAP) return false;
-    for (int i = threadIdx.x; i <= FZ_R; i += 512) rptr[i] = ptr[row0 + i] - ebase;
+    for (int i = threadIdx.x; i <= nrows; i += 512) rptr[i] = ptr[row0 + i] - ebase;
     for (int i = threadIdx.x; i < ne; i += 512) { ecol[i] = col[ebase + i]; evalv[i] = val[ebase + i]; }
     return true;
 }
-#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp, &tmask) \
-                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp, &tmask))
+#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp, &tmask, nrows) \
+                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp, &tmask, nrows))
 
 // ---- half-tile groups --------------------------------------------------------------------------------------
 // Waves 0-3 own rows [0, 64) of the tile and waves 4-7 rows [64, 128) in every phase (gather rows, MFMA A rows,
@@ -232,7 +245,25 @@ __device__ __forceinline__ void rm_st(const AccBuf& b, int v, f32x4 x, int coff 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), b.rs, b.vo + so, 0, 0);
 }
 
-#define FZ_FOR_ACC _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)
+#define FZ_FOR_ACC _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) if (rb < nrb) _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)
+
+// This wave's place in a tile of `nblk` live 32-row blocks.  Group g (waves 4 g .. 4 g + 3) owns blocks 2 g, 2 g + 1 in every
+// phase; a group without a live block leaves after the tile load (all four waves: the group counters and the row-major
+// I/O of a half tile count on whole groups).  nrb = this wave's live row blocks:
+//   D = 128: wave row wr in {0, 1} owns blocks 2 wr, 2 wr + 1 (RB = 2);  D = 64: wave row wr in 0..3 owns block wr (RB = 1).
+template <int D>
+__device__ __forceinline__ int fz_live(int nblk, int wr) {
+    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
+    const int live = nblk - wr * RB;
+    return live < 0 ? 0 : (live > RB ? RB : live);
+}
+#define FZ_TILE_SETUP()                                                          \
+    const int tile = blockIdx.x + a.tile0;                                      \
+    const int row0 = a.mt_row0 ? a.mt_row0[tile] : tile * FZ_R;                 \
+    const int nblk = a.mt_nblk ? a.mt_nblk[tile] : 4;                           \
+    const int nrows = nblk * 32;                                                \
+    const int nrb = fz_live<D>(nblk, wr);                                       \
+    const bool grp_live = nblk > 2 * grp
 
 #define FZ_GSYNC() grp_sync(gs)
 
@@ -257,8 +288,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x + a.tile0;
-    const int row0 = tile * FZ_R;
+    FZ_TILE_SETUP();
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;         // this lane's row for reg 0 of row block 0
@@ -273,12 +303,13 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     // and are not written when the caller passes no arrays for them
     const bool save = a.m != nullptr;
     // ---- h tile -> LDS ----
-    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+    for (int idx = tid; idx < nrows * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
         *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
     }
-    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv, nrows);
     __syncthreads();
+    if (!grp_live) return;                   // a short tile: this half has no rows
 
     // ---- message: m = sum_e AGG_e . W_e + wdeg_e * b_e   (models/ggnn.py:223-242) ----
     f32x16 acc_m[1][RB];
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
+        if (any && nrb > 0) tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot, &pre, nrb);
         FZ_GSYNC();
     }
     // first B fragments of the h-part of the gates: requested now, used after the m epilogue and its barrier
@@ -335,8 +366,10 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         for (int g = 0; g < NG; ++g) zero_acc(gg[g]);
         BPre<NG> pre_m;                                   // in flight under the h-part
         tile_b_prefetch<NG>(pre_m, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot);
-        tile_mma<NG, RB>(gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h);
-        tile_mma<NG, RB>(gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m);
+        if (nrb > 0) {
+            tile_mma<NG, RB>(gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h, nrb);
+            tile_mma<NG, RB>(gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m, nrb);
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -367,7 +400,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         f32x16 gc[1][RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
-        tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot, &pre_u);
+        if (nrb > 0) tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot, &pre_u, nrb);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
     }
@@ -417,8 +450,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x + a.tile0;
-    const int row0 = tile * FZ_R;
+    FZ_TILE_SETUP();
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
@@ -433,11 +465,16 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #define RM_ROW(v) (grp * 64 + ((v) * 256 + tg) / F4)
 #define RM_C4(v) (((v) * 256 + tg) % F4)
 #define RM_LDS(T, v) (*(f32x4*)((T) + RM_ROW(v) * LD + 4 * RM_C4(v)))
+#define RM_LIVE(v) (grp * 64 + (v) * (256 / F4) < nrows)          /* slot v's rows lie in a live 32-row block (uniform per group) */
     const AccBuf b_g = rm_buf<D, D>(a.dhout, row0, grp, tg), b_c = rm_buf<D, D>(a.c, row0, grp, tg);
     const AccBuf b_h = rm_buf<D, D>(a.h, row0, grp, tg), b_rz = rm_buf<D, 2 * D>(a.rz, row0, grp, tg);
     const AccBuf b_o = rm_buf<D, 7 * D>(a.gda, row0, grp, tg), b_dh = rm_buf<D, D>(a.dh, row0, grp, tg);
 
-    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);     // visible after the first barrier
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv, nrows);     // visible after the first barrier
+    if (!grp_live) {                         // a short tile: this half has no rows.  It has staged its share of the CSR; it
+        __syncthreads();                     // meets the first workgroup barrier and leaves (the hardware barrier stops
+        return;                              // counting waves that have ended)
+    }
 
     // ---- da_c = dh' z (1 - c^2) -> X ; da_z = dh' (c - h) z (1 - z) -> Y ; ex = dh' (1 - z): the direct part of dh ----
     f32x4 ex[NV];
@@ -445,14 +482,14 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
         f32x4 g4[NV], z4[NV], c4[NV], h4[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
+        for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) {
             g4[v] = rm_ld<D, D>(b_g, v);
             z4[v] = rm_ld<D, 2 * D>(b_rz, v, D);
             c4[v] = rm_ld<D, D>(b_c, v);
             if (!first) h4[v] = rm_ld<D, D>(b_h, v);
         }
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
+        for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) {
             const f32x4 gz = g4[v] * z4[v];
             const f32x4 dac = gz * (one - c4[v] * c4[v]);
             f32x4 dz = gz * (one - z4[v]);
@@ -477,24 +514,24 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 
     f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
     zero_acc(acc_x[0]); zero_acc(acc_x[1]);
-    tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c);       // [dh | dm] += da_c . A_c
+    if (nrb > 0) tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c, nrb);       // [dh | dm] += da_c . A_c
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
         zero_acc(acc_d[0]);
         {
             const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
-            tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot);
+            if (nrb > 0) tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot, nullptr, nrb);
         }
         FZ_GSYNC();                          // all waves of this half done with da_c in X
         FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_d[0][rb][reg]; }
         f32x4 r4[NV], h4[NV];                // in flight across the group barrier
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { r4[v] = rm_ld<D, 2 * D>(b_rz, v); h4[v] = rm_ld<D, D>(b_h, v); }
+        for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) { r4[v] = rm_ld<D, 2 * D>(b_rz, v); h4[v] = rm_ld<D, D>(b_h, v); }
         FZ_GSYNC();
         // da_r = d(r*h) h r (1-r) -> X (in place) ; ex += d(r*h) r
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
+        for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) {
             const f32x4 drh = RM_LDS(Xs, v);
             const f32x4 dr = drh * r4[v];
             const f32x4 dar = dr * h4[v] * ((f32x4){1.f, 1.f, 1.f, 1.f} - r4[v]);
@@ -505,12 +542,12 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         FZ_GSYNC();
         {
             const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
-            tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot);
+            if (nrb > 0) tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot, nullptr, nrb);
         }
     }
-    {   // da_z has been waiting in Y since the prologue
+    if (nrb > 0) {   // da_z has been waiting in Y since the prologue
         const float* const Bz[2] = {Az_h, Az_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Yw, LD, Bz, ld2, D, rot);
+        tile_mma<2, RB>(acc_x, Yw, LD, Bz, ld2, D, rot, nullptr, nrb);
     }
     FZ_GSYNC();                              // all waves of this half done with X and Y
     // ---- X <- dm ----
@@ -528,7 +565,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
         float wd;
         FZ_GATHER(Xs, Ys, e, &wd);
-        {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
+        if ((tid >> 2) < nrows) {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + row * LD + q * (D / 4);
             float* o = a.gda + (size_t)(row0 + row) * 7 * D + e * D + q * (D / 4);
@@ -538,14 +575,15 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
+        if (any && nrb > 0) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre, nrb);
         FZ_GSYNC();
     }
     // ---- dh = (MFMA part, via Y) + ex ----
     FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
     FZ_GSYNC();
 #pragma unroll
-    for (int v = 0; v < NV; ++v) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v) + ex[v]);
+    for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v) + ex[v]);
+#undef RM_LIVE
 #undef RM_ROW
 #undef RM_C4
 #undef RM_LDS
@@ -561,6 +599,7 @@ struct RelArgs {
     const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
     int tile0;                      // the launch covers tiles tile0 .. tile0 + gridDim.x - 1 (all arrays whole)
     int act;
+    const int* mt_row0; const int* mt_nblk;     // optional tile table, as StepArgs
     // forward
     const float* h;                 // [N x D]
     const float* WT;                // [4D x D]  K4-packed, rows e*D + k
@@ -598,8 +637,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x + a.tile0;
-    const int row0 = tile * FZ_R;
+    FZ_TILE_SETUP();
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
@@ -607,12 +645,13 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
     const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
     const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
 
-    for (int idx = tid; idx < FZ_R * (D / 4); idx += 512) {
+    for (int idx = tid; idx < nrows * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
         *(f32x4*)(Hs + r * LD + 4 * c4) = *(const f32x4*)(a.h + (size_t)(row0 + r) * D + 4 * c4);
     }
-    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv, nrows);
     __syncthreads();
+    if (!grp_live) return;                   // a short tile: this half has no rows
 
     f32x16 acc[1][RB];
     zero_acc(acc[0]);
@@ -631,10 +670,10 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma<1, RB>(acc, Aw, LD, Bp, ldw, D, rot, &pre);
+        if (any && nrb > 0) tile_mma<1, RB>(acc, Aw, LD, Bp, ldw, D, rot, &pre, nrb);
         FZ_GSYNC();
     }
-    tile_mma<1, RB>(acc, Hw, LD, Bs, lds_, D, rot, &pre_s);          // self connection: h . W_s^T
+    if (nrb > 0) tile_mma<1, RB>(acc, Hw, LD, Bs, lds_, D, rot, &pre_s, nrb);          // self connection: h . W_s^T
     {
         const AccBuf oo = acc_buf<D>(a.out, row0, lrow, col);
         float be[4];
@@ -649,7 +688,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
             acc_st<D>(oo, rb, reg, bmp_act(act, v));
         }
     }
-    if (a.wdeg != nullptr && (tid & 255) < 64) {   // this half's weighted degrees (written by this half's threads, group-synced
+    if (a.wdeg != nullptr && (tid & 255) < 64 && grp * 64 + (tid & 255) < nrows) {   // this half's weighted degrees (written by this half's threads, group-synced
                                                    // above); the backward's operand: not written in forward-only evaluation
         const int r = grp * 64 + (tid & 255);
         *(f32x4*)(a.wdeg + (size_t)(row0 + r) * 4) = *(const f32x4*)(wds + r * 4);
@@ -678,8 +717,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x + a.tile0;
-    const int row0 = tile * FZ_R;
+    FZ_TILE_SETUP();
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
@@ -691,18 +729,23 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
 #define RM_ROW(v) (grp * 64 + ((v) * 256 + tg) / F4)
 #define RM_C4(v) (((v) * 256 + tg) % F4)
 #define RM_LDS(T, v) (*(f32x4*)((T) + RM_ROW(v) * LD + 4 * RM_C4(v)))
+#define RM_LIVE(v) (grp * 64 + (v) * (256 / F4) < nrows)
     const AccBuf b_g = rm_buf<D, D>(a.dout, row0, grp, tg), b_y = rm_buf<D, D>(a.y, row0, grp, tg);
     const AccBuf b_o = rm_buf<D, 5 * D>(a.gda, row0, grp, tg), b_dh = rm_buf<D, D>(a.dh, row0, grp, tg);
 
-    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv);
+    const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv, nrows);
+    if (!grp_live) {                         // a short tile: this half has no rows (see k_ggnn_step_bwd)
+        __syncthreads();
+        return;
+    }
 
     {   // dpre = dout * act'(out) -> X and gda[:, 4D:]
         f32x4 g4[NV], y4[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { g4[v] = rm_ld<D, D>(b_g, v); y4[v] = rm_ld<D, D>(b_y, v); }
+        for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) { g4[v] = rm_ld<D, D>(b_g, v); y4[v] = rm_ld<D, D>(b_y, v); }
         const int act = a.act;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
+        for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) {
             f32x4 dp;
 #pragma unroll
             for (int t = 0; t < 4; ++t) dp[t] = g4[v][t] * bmp_dact(act, y4[v][t]);
@@ -718,7 +761,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
 
     f32x16 acc_h[1][RB];
     zero_acc(acc_h[0]);
-    tile_mma<1, RB>(acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s);        // dh = dpre . W_s
+    if (nrb > 0) tile_mma<1, RB>(acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s, nrb);        // dh = dpre . W_s
     for (int e = 0; e < 4; ++e) {
         const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
         const int ldw[1] = {4 * D};
@@ -726,7 +769,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
         tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
         float wd;
         FZ_GATHER(Xs, Ys, e, &wd);
-        {
+        if ((tid >> 2) < nrows) {
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + row * LD + q * (D / 4);
             float* o = a.gda + (size_t)(row0 + row) * 5 * D + e * D + q * (D / 4);
@@ -736,13 +779,14 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
+        if (any && nrb > 0) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre, nrb);
         FZ_GSYNC();
     }
     FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
     FZ_GSYNC();
 #pragma unroll
-    for (int v = 0; v < NV; ++v) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v));
+    for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v));
+#undef RM_LIVE
 #undef RM_ROW
 #undef RM_C4
 #undef RM_LDS
@@ -782,6 +826,7 @@ __global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
     const int rot = (blockIdx.x * 8) % D;
+    constexpr int nrb = RB;                  // (this kernel works on the per-instance layout: whole 128-row tiles)
     const float* Hw = Hs + (wrow0 + l31) * LD + 4 * hi;
     const float* Aw = As + (wrow0 + l31) * LD + 4 * hi;
     float* Al = As + lrow * LD + col;
@@ -890,11 +935,13 @@ static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
 // all NULL (forward-only evaluation: predict under no-backprop, train_binary.py:120-127).
 extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr,
                                  const int* csr_col, const float* csr_val, const float* WT, const float* bE, const float* AT,
-                                 const float* UcT, const float* b, float* m, float* rz, float* c, float* hout, hipStream_t st) {
+                                 const float* UcT, const float* b, float* m, float* rz, float* c, float* hout,
+                                 const int* mt_row0, const int* mt_nblk, hipStream_t st) {
     BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
     BMP_REQUIRE((m != nullptr) == (rz != nullptr) && (m != nullptr) == (c != nullptr) && hout != nullptr);
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0;
+    BMP_REQUIRE((mt_row0 != nullptr) == (mt_nblk != nullptr));
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
@@ -903,10 +950,11 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, 
 // [G_0..G_3 | da_r | da_z | da_c] for bmp_ggnn_step_wgrad.  Wnat [d x 4d], A [3d x 2d], Uc [d x d].
 extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d,
                                  int first, const int* csrT_ptr, const int* csrT_col, const float* csrT_val,
-                                 const float* Wnat, const float* A, const float* Uc, float* dh, float* gda, hipStream_t st) {
-    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+                                 const float* Wnat, const float* A, const float* Uc, float* dh, float* gda,
+                                 const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first;
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
@@ -1004,10 +1052,10 @@ static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
 // (bmp/functional.py:pack_k4).  Saves wdeg [N x 4].
 extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col,
                                     const float* csr_val, const float* WT, const float* bE, const float* WsT, const float* bs,
-                                    int act, float* out, float* wdeg, hipStream_t st) {
-    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
+                                    int act, float* out, float* wdeg, const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act; a.tile0 = tile0;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
     a.h = h; a.WT = WT; a.bE = bE; a.WsT = WsT; a.bs = bs; a.out = out; a.wdeg = wdeg;
     return d == 128 ? rel_launch<128>(false, a, n_tiles, st) : rel_launch<64>(false, a, n_tiles, st);
 }
@@ -1015,10 +1063,10 @@ extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int 
 // dh and gda [N x 5d] = [G_0..G_3 | dpre] for bmp_relgcn_layer_wgrad.  Wnat [d x 4d] = WT^T, Ws [d x d] = WsT^T, K4-packed.
 extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                                     const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
-                                    float* gda, hipStream_t st) {
-    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d));
+                                    float* gda, const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act;
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
     a.dout = dout; a.y = out; a.Wnat = Wnat; a.Ws = Ws; a.dh = dh; a.gda = gda;
     return d == 128 ? rel_launch<128>(true, a, n_tiles, st) : rel_launch<64>(true, a, n_tiles, st);
 }

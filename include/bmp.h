@@ -116,14 +116,18 @@ int bmp_gru_state_bwd(const float* dsout, const float* hd, const float* m, const
  * GEMM launch + ONE fixed-order reduction.  first != 0 (the GRU's first call after reset has no r gate): the da_r columns
  * of gda are neither written by bwd nor read by wgrad and count as zeros. */
 /* The forward launches take a tile range: tiles tile0 .. tile0 + n_tiles - 1 of the WHOLE arrays passed (a step is
- * tile-local: molecules never straddle tiles), so that two halves of a batch can run as two chains on two streams. */
+ * tile-local: molecules never straddle tiles), so that two halves of a batch can run as two chains on two streams.
+ * mt_row0 / mt_nblk (both NULL: tile t = rows [128 t, 128 t + 128)): the tile table of the encoder layout
+ * (bmp_collate_plan_enc) -- tile t = rows [mt_row0[t], mt_row0[t] + 32 mt_nblk[t]), 1 <= mt_nblk <= 4; a tile's dead
+ * blocks cost no gather, MFMA, load or store.  m, rz, c may be NULL together (forward-only evaluation). */
 int bmp_ggnn_step_supported(int d);
 int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
                       const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
-                      const float* b, float* m, float* rz, float* c, float* hout, bmp_stream_t stream);
+                      const float* b, float* m, float* rz, float* c, float* hout, const int* mt_row0, const int* mt_nblk,
+                      bmp_stream_t stream);
 int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
                       const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
-                      const float* Uc, float* dh, float* gda, bmp_stream_t stream);
+                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, bmp_stream_t stream);
 size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
 int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first,
                         float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats,
@@ -140,10 +144,10 @@ int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const f
 int bmp_relgcn_layer_supported(int d_in, int d_out);
 int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col, const float* csr_val,
                          const float* WT, const float* bE, const float* WsT, const float* bs, int act, float* out,
-                         float* wdeg, bmp_stream_t stream);
+                         float* wdeg, const int* mt_row0, const int* mt_nblk, bmp_stream_t stream);   /* wdeg may be NULL */
 int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                          const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
-                         float* gda, bmp_stream_t stream);
+                         float* gda, const int* mt_row0, const int* mt_nblk, bmp_stream_t stream);
 size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d);
 int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
                            float* cs, int accumulate, float* ws, size_t ws_floats, bmp_stream_t stream);
@@ -283,19 +287,28 @@ int bmp_collate_pair_meta(const int* tab, int I, int B, int side1_tiles, int R, 
 int bmp_collate_emit(const int* tab, int I, const int* st_rowoff, const int* st_eoff, const int* st_atom, const int* st_rend,
                      const int* st_rendT, const int* st_col, const int* st_colT, int* atom_id, float* row_w, int* row_mol,
                      int* csr_ptr, int* csr_col, float* csr_val, int* csrT_ptr, int* csrT_col, float* csrT_val,
-                     bmp_stream_t stream);
+                     const int* tile_last, bmp_stream_t stream);   /* tile_last: NULL, or bmp_collate_plan_enc's (pad-row marks) */
 
-/* ---- de-duplicated encoding of a pair batch ("de-duplication caveat": a batch of B pairs holds 2B molecule
- * instances of at most 544 distinct drugs, setting.py:30; an atom's state depends on its molecule alone, models/ggnn.py:584-654) ----
- * The encoder runs over the distinct molecules, the co-attention over the per-instance layout; these two index kernels connect
- * them.  row_mol [N_inst] / urow_mol [N_U]: instance / distinct molecule of every row (-1: none); inst_row0 [I], urow0 [U]: first
- * rows; uid [I]: distinct molecule of every instance; uptr [U + 1] / uinst: the instances of every distinct molecule, ascending.
- * bmp_molrows_expand: out[instance row] = hU[its molecule's row] (rows of no instance: 0).  bmp_molrows_reduce:
- * dhU[row] = sum over the molecule's instances, in that order, of dX[instance row] -- no atomics, bitwise reproducible. */
-int bmp_molrows_expand(const float* hU, int d, const int* row_mol, const int* inst_row0, const int* uid, const int* urow0,
-                       int N_inst, float* out, bmp_stream_t stream);
-int bmp_molrows_reduce(const float* dX, int d, const int* urow_mol, const int* urow0, const int* uptr, const int* uinst,
-                       const int* inst_row0, int N_U, float* dhU, bmp_stream_t stream);
+/* ---- the encoder's own row layout (csrc/bmp_enc.hip, bmp/enclayout.py) ----
+ * Inside the encoder the zero-padded positions of a batch (concat_mols, train_ddi_modify.py:296; unmasked everywhere,
+ * models/ggnn.py:340,603) all carry ONE state per propagation step: atom id 0, no bonds (models/ggnn.py:215-263).  The encoder
+ * layout holds the real atoms of every encoded molecule and one pad row per tile, in tiles of 1..4 live 32-row blocks sized so
+ * that the CUs finish together (bmp_collate_plan_enc, a HOST function like bmp_collate_plan); with dedup != 0 a molecule that
+ * occurs several times in the batch is encoded once (SURVEY.md 8(d) caveat; at most 544 distinct drugs, setting.py:30).  The
+ * readout and the co-attention keep the per-instance layout; two index kernels connect the layouts:
+ *   bmp_encrows_expand: out[instance row] = h[encoder row of that atom] (an instance's pad row <- its tile's pad row; rows of
+ *                       no instance: 0);
+ *   bmp_encrows_reduce: dh[encoder row] = sum of dX over the instance rows copied from it, in a fixed order (no atomics).
+ * Table meanings: see csrc/bmp_collate.hip (bmp_collate_plan_enc) and csrc/bmp_enc.hip.  bmp_collate_plan_enc returns -2000
+ * when a molecule has more than 127 atoms (the batch then keeps the per-instance layout). */
+int bmp_collate_plan_enc(const int* st_nrows, const int* st_nedges, int n_store, const int* mids, int I, int dedup, int n_cu,
+                         int R, int* tab, int* tile_last, int* uid, int* uptr, int* uinst, int* enc_pad, int* tptr, int* tmols,
+                         int* mt_row0, int* mt_nblk, long long* totals);
+int bmp_encrows_expand(const float* h, int d, const int* row_mol, const int* inst_row0, const int* uid, const int* enc_row0,
+                       const int* enc_n, const int* enc_pad, int N_inst, float* out, bmp_stream_t stream);
+int bmp_encrows_reduce(const float* dX, int d, const int* erow_mol, const int* enc_row0, const int* enc_n, const int* uptr,
+                       const int* uinst, const int* inst_row0, const int* tptr, const int* tmols, int N_enc, float* dh,
+                       bmp_stream_t stream);
 
 /* rescale_adj -- models/relgcn.py:20-28 on the packed CSR: csr_val_out[e] = csr_val[e] * (1 / deg(source of e)), and the
  * same for the transposed CSR; deg = sum of the source atom's bond values over types and destinations (0 -> 1). */

@@ -19,12 +19,8 @@ def _run(args, extra_env=None, timeout=240):
 
 
 def _reports(out):
-    recs = []
-    for ln in out.splitlines():
-        ln = ln.strip()
-        if ln.startswith("{") and '"rank_check"' in ln:
-            recs.append(json.loads(ln))
-    return recs
+    import re
+    return [json.loads(m) for m in re.findall(r'\{"rank_check"[^{}]*\}', out)]       # (ranks share one stdout)
 
 
 def test_gpus_2_without_torchrun_starts_two_ranks():
