@@ -295,7 +295,9 @@ def main():
             balanced over the CUs; every molecule INSTANCE encoded unless ``dedup``).  BMP_BENCH_LAYOUT=instance: the
             per-instance batch alone (round 2's form)."""
             lo = k * (gbatch or B * world) + rank * B
-            if LAYOUT == "instance" and not dedup:
+            # (the encoder layout pays through the fused tile kernels, d = 64 / 128; the row-wise operators of other widths
+            #  gain nothing from tile heights and would only carry the two extra index launches)
+            if (LAYOUT == "instance" or self.cfg["d"] not in (64, 128)) and not dedup:
                 return packed.pack_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B])
             return enclayout.encode_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B], dedup=dedup)
 

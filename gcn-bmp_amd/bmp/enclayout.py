@@ -214,7 +214,7 @@ def expand_rows_host(h: torch.Tensor, eb: EncBatch) -> torch.Tensor:
     u = eb.uid.long()[inst]
     l = torch.arange(pb.n_rows, device=h.device) - pb.mol_row0.long()[inst]
     src = torch.where(l < eb.enc_n.long()[u], eb.enc_row0.long()[u] + l, eb.enc_pad.long()[u])
-    out = h[src.clamp(max=h.shape[0] - 1)]
+    out = h[src.clamp(0, h.shape[0] - 1)]
     return torch.where(live[:, None], out, torch.zeros_like(out))
 
 

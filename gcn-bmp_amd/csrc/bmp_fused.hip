@@ -25,6 +25,7 @@ struct StepArgs {
     // optional tile table (nullptr: tile t = rows [128 t, 128 t + 128)): tile t = rows [mt_row0[t], + 32 * mt_nblk[t]),
     // mt_nblk in 1..4 -- tiles of fewer live 32-row blocks skip the dead blocks' gathers, MFMAs, loads and stores
     const int* mt_row0; const int* mt_nblk;
+    int mt_rows;                    // rows of the launch's tiles when a table is given (host-side accounting only)
     // forward
     const float* h;                 // [N x D] step input
     const float* WT;                // [4D x D]  message weights, K-major (row e*D + k, col c)
@@ -62,10 +63,11 @@ __device__ __forceinline__ void tile_b_prefetch(BPre<NB>& p, const float* const 
     }
 }
 
-// `nrb` (<= RB): live row blocks of this wave (tiles of fewer than four 32-row blocks); the others' A loads and MFMAs are skipped.
-template <int NB, int RB>
+// NRB (<= RB): live row blocks of this wave (a short tile of the encoder layout); the other blocks' A loads and MFMAs do not
+// exist in that instance.
+template <int NB, int RB, int NRB = RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr, int nrb = RB) {
+                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
     // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
     // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
     // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
@@ -80,35 +82,42 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
             b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
         }
     }
-    f32x4 a0[RB], a1[RB];            // A fragments (LDS) run one k-step ahead
+    f32x4 a0[NRB], a1[NRB];          // A fragments (LDS) run one k-step ahead
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) a0[rb] = (RB == 1 || rb < nrb) ? *(const f32x4*)(As_wave + rb * 32 * LD + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < NRB; ++rb) a0[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
     for (int it = 0; it < K; it += 8) {
         int k2 = k1 + 8; if (k2 >= K) k2 -= K;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b2[nb] = *(const f32x4*)(Bp[nb] + (size_t)k2 * ldw[nb]);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) a1[rb] = (RB == 1 || rb < nrb) ? *(const f32x4*)(As_wave + rb * 32 * LD + k1) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < NRB; ++rb) a1[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k1);
         __builtin_amdgcn_sched_barrier(0);
-        if (RB == 1 || nrb == RB) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(a0[rb][t], b0[nb][t], acc[nb][rb]);
-        } else {                         // a short tile: row block 0 only (RB == 2)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][0] = bmp_mfma(a0[0][t], b0[nb][t], acc[nb][0]);
-        }
+                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(a0[rb][t], b0[nb][t], acc[nb][rb]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) { b0[nb] = b1[nb]; b1[nb] = b2[nb]; }
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) a0[rb] = a1[rb];
+        for (int rb = 0; rb < NRB; ++rb) a0[rb] = a1[rb];
         k = k1; k1 = k2;
+    }
+}
+
+// tile_mma for a wave with `nrb` live row blocks (0: nothing to do).  VAR == false: whole tiles, nrb == RB at compile time.
+template <bool VAR, int NB, int RB>
+__device__ __forceinline__ void tile_mma_n(int nrb, f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
+                                           const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
+    if constexpr (!VAR) {
+        tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+    } else if constexpr (RB == 1) {
+        if (nrb > 0) tile_mma<NB, 1, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+    } else {
+        if (nrb == RB) tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+        else if (nrb > 0) tile_mma<NB, RB, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
     }
 }
 
@@ -136,7 +145,7 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
     float wd = 0.f;
     bool any = false;
     *wsum = 0.f;
-    if (row >= nrows) return false;           // a dead block of a short tile: nothing reads its rows
+    if (nrows < FZ_R && row >= nrows) return false;       // a dead block of a short tile: nothing reads its rows
     const int e0 = ptr[row], e1 = ptr[row + 1];
     for (int ed = e0; ed < e1; ++ed) {
         const int cv = col[ed];
@@ -257,17 +266,18 @@ __device__ __forceinline__ int fz_live(int nblk, int wr) {
     const int live = nblk - wr * RB;
     return live < 0 ? 0 : (live > RB ? RB : live);
 }
+// (VAR == false -- whole 128-row tiles, no table -- folds every one of these to a constant)
 #define FZ_TILE_SETUP()                                                          \
     const int tile = blockIdx.x + a.tile0;                                      \
-    const int row0 = a.mt_row0 ? a.mt_row0[tile] : tile * FZ_R;                 \
-    const int nblk = a.mt_nblk ? a.mt_nblk[tile] : 4;                           \
-    const int nrows = nblk * 32;                                                \
-    const int nrb = fz_live<D>(nblk, wr);                                       \
-    const bool grp_live = nblk > 2 * grp
+    const int row0 = VAR ? a.mt_row0[tile] : tile * FZ_R;                       \
+    const int nblk = VAR ? a.mt_nblk[tile] : 4;                                 \
+    const int nrows = VAR ? nblk * 32 : FZ_R;                                   \
+    const int nrb = VAR ? fz_live<D>(nblk, wr) : RB;                            \
+    const bool grp_live = VAR ? nblk > 2 * grp : true
 
 #define FZ_GSYNC() grp_sync(gs)
 
-template <int D, bool FIRST>
+template <int D, bool FIRST, bool VAR>
 __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 
     // forward-only evaluation (predict under no-backprop, train_binary.py:120-127): m, r|z and c are the backward's inputs
     // and are not written when the caller passes no arrays for them
-    const bool save = a.m != nullptr;
+    const bool save = a.m != nullptr;        // (one program for both: predict's logits are bit for bit the training forward's)
     // ---- h tile -> LDS ----
     for (int idx = tid; idx < nrows * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any && nrb > 0) tile_mma<1, RB>(acc_m, Aw, LD, Bp, ldw, D, rot, &pre, nrb);
+        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
     // first B fragments of the h-part of the gates: requested now, used after the m epilogue and its barrier
@@ -366,10 +376,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         for (int g = 0; g < NG; ++g) zero_acc(gg[g]);
         BPre<NG> pre_m;                                   // in flight under the h-part
         tile_b_prefetch<NG>(pre_m, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot);
-        if (nrb > 0) {
-            tile_mma<NG, RB>(gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h, nrb);
-            tile_mma<NG, RB>(gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m, nrb);
-        }
+        tile_mma_n<VAR, NG, RB>(nrb, gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h);
+        tile_mma_n<VAR, NG, RB>(nrb, gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         f32x16 gc[1][RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
-        if (nrb > 0) tile_mma<1, RB>(gc, Aw, LD, Bu, ldu, D, rot, &pre_u, nrb);
+        tile_mma_n<VAR, 1, RB>(nrb, gc, Aw, LD, Bu, ldu, D, rot, &pre_u);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
     }
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 // MFMA A operands; what the MFMAs produce in accumulator layout (d(r*h), dm, dh) crosses to row-major
 // through the LDS tile it has to visit anyway.  (Accumulator-layout dword loads/stores of the same arrays
 // cost 64 + 30 us of a 287 us launch.)
-template <int D, bool FIRST>
+template <int D, bool FIRST, bool VAR>
 __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #define RM_ROW(v) (grp * 64 + ((v) * 256 + tg) / F4)
 #define RM_C4(v) (((v) * 256 + tg) % F4)
 #define RM_LDS(T, v) (*(f32x4*)((T) + RM_ROW(v) * LD + 4 * RM_C4(v)))
-#define RM_LIVE(v) (grp * 64 + (v) * (256 / F4) < nrows)          /* slot v's rows lie in a live 32-row block (uniform per group) */
+#define RM_LIVE(v) (!VAR || grp * 64 + (v) * (256 / F4) < nrows)  /* slot v's rows lie in a live 32-row block (uniform per group) */
     const AccBuf b_g = rm_buf<D, D>(a.dhout, row0, grp, tg), b_c = rm_buf<D, D>(a.c, row0, grp, tg);
     const AccBuf b_h = rm_buf<D, D>(a.h, row0, grp, tg), b_rz = rm_buf<D, 2 * D>(a.rz, row0, grp, tg);
     const AccBuf b_o = rm_buf<D, 7 * D>(a.gda, row0, grp, tg), b_dh = rm_buf<D, D>(a.dh, row0, grp, tg);
@@ -514,14 +522,14 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 
     f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
     zero_acc(acc_x[0]); zero_acc(acc_x[1]);
-    if (nrb > 0) tile_mma<2, RB>(acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c, nrb);       // [dh | dm] += da_c . A_c
+    tile_mma_n<VAR, 2, RB>(nrb, acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c);       // [dh | dm] += da_c . A_c
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
         zero_acc(acc_d[0]);
         {
             const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
-            if (nrb > 0) tile_mma<1, RB>(acc_d, Xw, LD, Bu, ldu, D, rot, nullptr, nrb);
+            tile_mma_n<VAR, 1, RB>(nrb, acc_d, Xw, LD, Bu, ldu, D, rot);
         }
         FZ_GSYNC();                          // all waves of this half done with da_c in X
         FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_d[0][rb][reg]; }
@@ -542,12 +550,12 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         FZ_GSYNC();
         {
             const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
-            if (nrb > 0) tile_mma<2, RB>(acc_x, Xw, LD, Br, ld2, D, rot, nullptr, nrb);
+            tile_mma_n<VAR, 2, RB>(nrb, acc_x, Xw, LD, Br, ld2, D, rot);
         }
     }
-    if (nrb > 0) {   // da_z has been waiting in Y since the prologue
+    {   // da_z has been waiting in Y since the prologue
         const float* const Bz[2] = {Az_h, Az_h + 4 * D};
-        tile_mma<2, RB>(acc_x, Yw, LD, Bz, ld2, D, rot, nullptr, nrb);
+        tile_mma_n<VAR, 2, RB>(nrb, acc_x, Yw, LD, Bz, ld2, D, rot);
     }
     FZ_GSYNC();                              // all waves of this half done with X and Y
     // ---- X <- dm ----
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any && nrb > 0) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre, nrb);
+        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
     // ---- dh = (MFMA part, via Y) + ex ----
@@ -600,6 +608,7 @@ struct RelArgs {
     int tile0;                      // the launch covers tiles tile0 .. tile0 + gridDim.x - 1 (all arrays whole)
     int act;
     const int* mt_row0; const int* mt_nblk;     // optional tile table, as StepArgs
+    int mt_rows;
     // forward
     const float* h;                 // [N x D]
     const float* WT;                // [4D x D]  K4-packed, rows e*D + k
@@ -616,7 +625,7 @@ struct RelArgs {
     float* gda;                     // [N x 5D]: G_0..G_3 (transposed gather of dpre per bond type) | dpre
 };
 
-template <int D>
+template <int D, bool VAR>
 __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -670,10 +679,10 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any && nrb > 0) tile_mma<1, RB>(acc, Aw, LD, Bp, ldw, D, rot, &pre, nrb);
+        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc, Aw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
-    if (nrb > 0) tile_mma<1, RB>(acc, Hw, LD, Bs, lds_, D, rot, &pre_s, nrb);          // self connection: h . W_s^T
+    tile_mma_n<VAR, 1, RB>(nrb, acc, Hw, LD, Bs, lds_, D, rot, &pre_s);          // self connection: h . W_s^T
     {
         const AccBuf oo = acc_buf<D>(a.out, row0, lrow, col);
         float be[4];
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
     }
 }
 
-template <int D>
+template <int D, bool VAR>
 __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
 #define RM_ROW(v) (grp * 64 + ((v) * 256 + tg) / F4)
 #define RM_C4(v) (((v) * 256 + tg) % F4)
 #define RM_LDS(T, v) (*(f32x4*)((T) + RM_ROW(v) * LD + 4 * RM_C4(v)))
-#define RM_LIVE(v) (grp * 64 + (v) * (256 / F4) < nrows)
+#define RM_LIVE(v) (!VAR || grp * 64 + (v) * (256 / F4) < nrows)
     const AccBuf b_g = rm_buf<D, D>(a.dout, row0, grp, tg), b_y = rm_buf<D, D>(a.y, row0, grp, tg);
     const AccBuf b_o = rm_buf<D, 5 * D>(a.gda, row0, grp, tg), b_dh = rm_buf<D, D>(a.dh, row0, grp, tg);
 
@@ -761,7 +770,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
 
     f32x16 acc_h[1][RB];
     zero_acc(acc_h[0]);
-    if (nrb > 0) tile_mma<1, RB>(acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s, nrb);        // dh = dpre . W_s
+    tile_mma_n<VAR, 1, RB>(nrb, acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s);        // dh = dpre . W_s
     for (int e = 0; e < 4; ++e) {
         const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
         const int ldw[1] = {4 * D};
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any && nrb > 0) tile_mma<1, RB>(acc_h, Yw, LD, Bp, ldw, D, rot, &pre, nrb);
+        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
     FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
@@ -906,28 +915,31 @@ static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 
 
 extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 
-template <int D, bool FIRST>
-static int fz_launch2(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
-    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST> : (const void*)k_ggnn_step_fwd<D, FIRST>;
+// `rows`: rows the launch works on (flop / byte accounting of the roofline leg: with a tile table the live rows, passed by the caller).
+template <int D, bool FIRST, bool VAR>
+static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, double rows, hipStream_t st) {
+    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, VAR> : (const void*)k_ggnn_step_fwd<D, FIRST, VAR>;
     static bool attr_set[2] = {false, false};      // per template instance, per direction: set once, not per launch
     if (!attr_set[bwd ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
         if (e != hipSuccess) return (int)e;
         attr_set[bwd ? 1 : 0] = true;
     }
-    const double rows = (double)n_tiles * FZ_R;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
                       4.0 * rows * D * (bwd ? 13.0 : 6.0), st, FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER);
-    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
 }
 
 template <int D>
 static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
-    return a.first ? fz_launch2<D, true>(bwd, a, n_tiles, st) : fz_launch2<D, false>(bwd, a, n_tiles, st);
+    const double rows = a.mt_row0 != nullptr ? (double)a.mt_rows : (double)n_tiles * FZ_R;
+    if (a.mt_row0 != nullptr)
+        return a.first ? fz_launch3<D, true, true>(bwd, a, n_tiles, rows, st) : fz_launch3<D, false, true>(bwd, a, n_tiles, rows, st);
+    return a.first ? fz_launch3<D, true, false>(bwd, a, n_tiles, rows, st) : fz_launch3<D, false, false>(bwd, a, n_tiles, rows, st);
 }
 
 // One GGNN propagation step, forward (models/ggnn.py:215-263): m = message(h), h' = GRU([h, m]).
@@ -936,12 +948,12 @@ static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
 extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr,
                                  const int* csr_col, const float* csr_val, const float* WT, const float* bE, const float* AT,
                                  const float* UcT, const float* b, float* m, float* rz, float* c, float* hout,
-                                 const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+                                 const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
     BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
     BMP_REQUIRE((m != nullptr) == (rz != nullptr) && (m != nullptr) == (c != nullptr) && hout != nullptr);
     StepArgs a; memset(&a, 0, sizeof(a));
     BMP_REQUIRE((mt_row0 != nullptr) == (mt_nblk != nullptr));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
@@ -951,10 +963,10 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, 
 extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d,
                                  int first, const int* csrT_ptr, const int* csrT_col, const float* csrT_val,
                                  const float* Wnat, const float* A, const float* Uc, float* dh, float* gda,
-                                 const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+                                 const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
@@ -1030,32 +1042,36 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
 // ---- fused RelGCN layer (d_in == d_out in {64, 128}) ----
 extern "C" int bmp_relgcn_layer_supported(int d_in, int d_out) { return d_in == d_out && bmp_ggnn_step_supported(d_in); }
 
-template <int D>
-static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
-    const void* fn = bwd ? (const void*)k_relgcn_layer_bwd<D> : (const void*)k_relgcn_layer_fwd<D>;
+template <int D, bool VAR>
+static int rel_launch2(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
+    const void* fn = bwd ? (const void*)k_relgcn_layer_bwd<D, VAR> : (const void*)k_relgcn_layer_fwd<D, VAR>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[bwd ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
         if (e != hipSuccess) return (int)e;
         attr_set[bwd ? 1 : 0] = true;
     }
-    const double rows = (double)n_tiles * FZ_R;
+    const double rows = VAR ? (double)a.mt_rows : (double)n_tiles * FZ_R;
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * 5.0 * D * D, 4.0 * rows * D * (bwd ? 8.0 : 2.0), st,
                       BMP_KID_RELGCN);
-    if (bwd) hipLaunchKernelGGL((k_relgcn_layer_bwd<D>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_relgcn_layer_fwd<D>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    if (bwd) hipLaunchKernelGGL((k_relgcn_layer_bwd<D, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_relgcn_layer_fwd<D, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
+}
+template <int D>
+static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
+    return a.mt_row0 != nullptr ? rel_launch2<D, true>(bwd, a, n_tiles, st) : rel_launch2<D, false>(bwd, a, n_tiles, st);
 }
 
 // out = act(h . WsT + bs + sum_e gather_e(h) . WT_e + wdeg_e * bE_e); WT [4d x d] and WsT [d x d] K4-packed
 // (bmp/functional.py:pack_k4).  Saves wdeg [N x 4].
 extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col,
                                     const float* csr_val, const float* WT, const float* bE, const float* WsT, const float* bs,
-                                    int act, float* out, float* wdeg, const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+                                    int act, float* out, float* wdeg, const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
     BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.h = h; a.WT = WT; a.bE = bE; a.WsT = WsT; a.bs = bs; a.out = out; a.wdeg = wdeg;
     return d == 128 ? rel_launch<128>(false, a, n_tiles, st) : rel_launch<64>(false, a, n_tiles, st);
 }
@@ -1063,10 +1079,10 @@ extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int 
 // dh and gda [N x 5d] = [G_0..G_3 | dpre] for bmp_relgcn_layer_wgrad.  Wnat [d x 4d] = WT^T, Ws [d x d] = WsT^T, K4-packed.
 extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                                     const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
-                                    float* gda, const int* mt_row0, const int* mt_nblk, hipStream_t st) {
+                                    float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk;
+    a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.dout = dout; a.y = out; a.Wnat = Wnat; a.Ws = Ws; a.dh = dh; a.gda = gda;
     return d == 128 ? rel_launch<128>(true, a, n_tiles, st) : rel_launch<64>(true, a, n_tiles, st);
 }

@@ -119,15 +119,16 @@ int bmp_gru_state_bwd(const float* dsout, const float* hd, const float* m, const
  * tile-local: molecules never straddle tiles), so that two halves of a batch can run as two chains on two streams.
  * mt_row0 / mt_nblk (both NULL: tile t = rows [128 t, 128 t + 128)): the tile table of the encoder layout
  * (bmp_collate_plan_enc) -- tile t = rows [mt_row0[t], mt_row0[t] + 32 mt_nblk[t]), 1 <= mt_nblk <= 4; a tile's dead
- * blocks cost no gather, MFMA, load or store.  m, rz, c may be NULL together (forward-only evaluation). */
+ * blocks cost no gather, MFMA, load or store; mt_rows = the rows of the launch's tiles (the event timer's flop accounting,
+ * ignored without a table).  m, rz, c may be NULL together (forward-only evaluation). */
 int bmp_ggnn_step_supported(int d);
 int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
                       const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
                       const float* b, float* m, float* rz, float* c, float* hout, const int* mt_row0, const int* mt_nblk,
-                      bmp_stream_t stream);
+                      int mt_rows, bmp_stream_t stream);
 int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
                       const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
-                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, bmp_stream_t stream);
+                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
 size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
 int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first,
                         float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats,
@@ -144,10 +145,10 @@ int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const f
 int bmp_relgcn_layer_supported(int d_in, int d_out);
 int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col, const float* csr_val,
                          const float* WT, const float* bE, const float* WsT, const float* bs, int act, float* out,
-                         float* wdeg, const int* mt_row0, const int* mt_nblk, bmp_stream_t stream);   /* wdeg may be NULL */
+                         float* wdeg, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);   /* wdeg may be NULL */
 int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                          const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
-                         float* gda, const int* mt_row0, const int* mt_nblk, bmp_stream_t stream);
+                         float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
 size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d);
 int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
                            float* cs, int accumulate, float* ws, size_t ws_floats, bmp_stream_t stream);

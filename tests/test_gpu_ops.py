@@ -454,14 +454,14 @@ def test_step_and_layer_forward_over_tile_ranges_equal_the_whole_launch(fn, batc
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
         for t0, nt in ranges:
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, 0, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), ptr(WTp), ptr(bE),
-                                      ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout), stream()), "step")
+                                      ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout), None, None, 0, stream()), "step")
         return m, rz, c, hout
 
     def layer(ranges):
         out, wdeg = f(N, d), f(N, 4)
         for t0, nt in ranges:
             check(L.bmp_relgcn_layer_fwd(ptr(h), t0, nt, d, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), ptr(WTp), ptr(bE),
-                                         ptr(WsTp), ptr(bs), 2, ptr(out), ptr(wdeg), stream()), "layer")
+                                         ptr(WsTp), ptr(bs), 2, ptr(out), ptr(wdeg), None, None, 0, stream()), "layer")
         return out, wdeg
 
     for run in (step, layer):

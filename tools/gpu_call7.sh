@@ -1,8 +1,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_enclayout.py -q -x > gpurun_out/t_enc.log 2>&1 || (tail -60 gpurun_out/t_enc.log; exit 1)
-tail -n 3 gpurun_out/t_enc.log
+true
+true
 timeout -k 10 700 python -m pytest tests -m gpu -q -x > gpurun_out/t_gpu.log 2>&1 || (tail -60 gpurun_out/t_gpu.log; exit 1)
 tail -n 3 gpurun_out/t_gpu.log
 B="python bench.py --no-cpu-baseline --no-extras --steps 40 --warmup 6"
