@@ -226,7 +226,12 @@ def main():
         dist.barrier()
     from bmp import synth, packed, _lib, enclayout
     from bmp.predictor import build_pair_predictor
-    LAYOUT = os.environ.get("BMP_BENCH_LAYOUT", "encoder")
+    # Layout the encoder works on, per leg (BMP_BENCH_LAYOUT=encoder|instance forces one everywhere).  Measured on MI355X
+    # (DESIGN.md 3a''): the encoder layout's balanced tile heights make the fused kernels 4-8 % shorter, the two index launches
+    # and the second host plan cost about as much at 1024 pairs on c2 (352 k vs 354 k pairs/s), c3 gains 1.7 %, the
+    # 32-pair batch 14 % (its tiles spread over four times as many CUs); de-duplication always uses it.
+    LAYOUT = os.environ.get("BMP_BENCH_LAYOUT", "auto")
+    AUTO = {"c2": "instance", "c3": "encoder", "c4": "instance"}
     from bmp.dp import FlatAdam
     L = _lib.lib()
 
@@ -289,7 +294,7 @@ def main():
             self.alg_f = algorithmic_flops_per_pair(c, self.atoms_per_pair)
             self.alg_b = algorithmic_bytes_per_pair(c, self.atoms_per_pair, self.edges_per_pair)
 
-        def collate(self, i1, i2, lab, k, B=PAIRS_PER_GPU, gbatch=None, dedup=False):
+        def collate(self, i1, i2, lab, k, B=PAIRS_PER_GPU, gbatch=None, dedup=False, layout=None):
             """Global batch k of the pair list (i1, i2, lab): this rank's shard, packed on the device -- the per-instance
             batch and, for the encoder, the encoder layout (bmp/enclayout.py: real atoms + one pad row per tile, tile heights
             balanced over the CUs; every molecule INSTANCE encoded unless ``dedup``).  BMP_BENCH_LAYOUT=instance: the
@@ -297,7 +302,8 @@ def main():
             lo = k * (gbatch or B * world) + rank * B
             # (the encoder layout pays through the fused tile kernels, d = 64 / 128; the row-wise operators of other widths
             #  gain nothing from tile heights and would only carry the two extra index launches)
-            if (LAYOUT == "instance" or self.cfg["d"] not in (64, 128)) and not dedup:
+            layout = layout or (AUTO[self.name] if LAYOUT == "auto" else LAYOUT)
+            if (layout == "instance" or self.cfg["d"] not in (64, 128)) and not dedup:
                 return packed.pack_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B])
             return enclayout.encode_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B], dedup=dedup)
 
@@ -397,6 +403,7 @@ def main():
 
     env = Env(args.config)
     atoms_per_pair_main, real_row_fraction_main = env.atoms_per_pair, env.n_atoms / env.n_rows
+    env_main_batch0 = env.batches[0][0]
     cfg, store, idx1, idx2, label = env.cfg, env.store, env.idx1, env.idx2, env.label
     gb, steps_per_epoch, batches, dstore, opt = env.gb, env.steps_per_epoch, env.batches, env.dstore, env.opt
 
@@ -415,7 +422,7 @@ def main():
                     perm = np.random.RandomState(1000 + state["epoch"]).permutation(len(idx1))
                     state["p"] = (idx1[perm], idx2[perm], label[perm])
                 t0 = time.perf_counter()
-                pb, t = env.collate(*state["p"], i, B=state["B"])
+                pb, t = env.collate(*state["p"], i, B=state["B"], layout=state.get("layout"))
                 host_ms.append(time.perf_counter() - t0)
                 env.train_step(pb, t)
             return body
@@ -442,7 +449,7 @@ def main():
                         "the host runs ahead of the GPU.  One epoch: fresh permutation, per step host plan + pinned H2D (plan table, labels, pair metadata) + "
                         "bmp_collate_emit from the HBM-resident store, then the training step; nothing pre-packed")
         if args.config == "c2" and world == 1:
-            st = dict(epoch=1, B=32)
+            st = dict(epoch=1, B=32, layout=None if LAYOUT != "auto" else "encoder")
             body = epoch_body(st)
             for i in range(10):
                 body(i)
@@ -455,7 +462,9 @@ def main():
                 prof.disable()
                 pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
             b32 = dict(value=round(32 * n32 / dt_32, 1), unit="pairs/s", steps=n32, ms_per_step=round(1e3 * dt_32 / n32, 3),
-                       what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end")
+                       layout=st["layout"] or LAYOUT,
+                       what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end; the "
+                            "encoder layout gives every molecule a tile of its own height, spread over the CUs")
         if world == 1:
             # ---- forward-only leg: the evaluation callers' predict (eval_coattention.py:103-124; the evaluator extensions run
             #      it over the train and validation sets every epoch, training/extensions/batch_evaluator.py:49-100) ----
@@ -523,7 +532,7 @@ def main():
                                    f"{steps_per_epoch} batches of one epoch resident in HBM, cycled",
                        "layout": ("encoder layout: real atoms + one pad row per tile, tiles of 1..4 live 32-row blocks balanced over "
                                   "the 256 CUs (bmp/enclayout.py); readout and co-attention on the per-instance rows")
-                       if LAYOUT != "instance" else "per-instance packed layout, whole 128-row tiles",
+                       if hasattr(env_main_batch0, "pb_enc") else "per-instance packed layout, whole 128-row tiles",
                        "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": gb, "parallelism": f"dp{world}",
                        "atoms_per_pair": round(atoms_per_pair_main, 2), "real_row_fraction": round(real_row_fraction_main, 4),
                        "loss": round(loss_val, 5)},

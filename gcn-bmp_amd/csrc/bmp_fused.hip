@@ -277,7 +277,9 @@ __device__ __forceinline__ int fz_live(int nblk, int wr) {
 
 #define FZ_GSYNC() grp_sync(gs)
 
-template <int D, bool FIRST, bool VAR>
+// SAVE == false: forward-only evaluation (m, r|z, c are not kept).  The epilogues' arithmetic is written with explicit fused
+// multiply-adds so that both instances round alike: predict's logits are bit for bit the training forward's.
+template <int D, bool FIRST, bool VAR, bool SAVE>
 __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
 
     // forward-only evaluation (predict under no-backprop, train_binary.py:120-127): m, r|z and c are the backward's inputs
     // and are not written when the caller passes no arrays for them
-    const bool save = a.m != nullptr;        // (one program for both: predict's logits are bit for bit the training forward's)
+    constexpr bool save = SAVE;              // (the launcher picks the instance: a.m != nullptr)
     // ---- h tile -> LDS ----
     for (int idx = tid; idx < nrows * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx % (D / 4);
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         FZ_FOR_ACC {
             const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
             const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
-            const float v = acc_m[0][rb][reg] + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
+            const float v = __builtin_fmaf(wd4[3], be[3], __builtin_fmaf(wd4[2], be[2], __builtin_fmaf(wd4[1], be[1],
+                                           __builtin_fmaf(wd4[0], be[0], acc_m[0][rb][reg]))));
             Al[LOFF(rb, reg)] = v;
             if (save) acc_st<D>(mo, rb, reg, v);
         }
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             const float cv = bmp_tanh(acc_g[2][rb][reg] + bcn);
             const float zv = acc_g[1][rb][reg];
             float hn = zv * cv;
-            if (!FIRST) hn += (1.f - zv) * Hl[LOFF(rb, reg)];
+            if (!FIRST) hn = __builtin_fmaf(1.f - zv, Hl[LOFF(rb, reg)], hn);
             if (save) acc_st<D>(co, rb, reg, cv);
             acc_st<D>(ho, rb, reg, hn);
         }
@@ -918,18 +921,21 @@ extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 // `rows`: rows the launch works on (flop / byte accounting of the roofline leg: with a tile table the live rows, passed by the caller).
 template <int D, bool FIRST, bool VAR>
 static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, double rows, hipStream_t st) {
-    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, VAR> : (const void*)k_ggnn_step_fwd<D, FIRST, VAR>;
-    static bool attr_set[2] = {false, false};      // per template instance, per direction: set once, not per launch
-    if (!attr_set[bwd ? 1 : 0]) {
+    const int kind = bwd ? 2 : (a.m != nullptr ? 0 : 1);      // forward keeping m / rz / c, forward-only evaluation, backward
+    const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, VAR>
+                         : (kind == 0 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true> : (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false>);
+    static bool attr_set[3] = {false, false, false};      // per template instance, per kind: set once, not per launch
+    if (!attr_set[kind]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
         if (e != hipSuccess) return (int)e;
-        attr_set[bwd ? 1 : 0] = true;
+        attr_set[kind] = true;
     }
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
                       4.0 * rows * D * (bwd ? 13.0 : 6.0), st, FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER);
     if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else if (kind == 0) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
 }

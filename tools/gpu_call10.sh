@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for L in encoder instance; do
+for L in encoder instance; do echo $L;
 BMP_BENCH_LAYOUT=$L BMP_BENCH_OTHERS=0 python bench.py --no-cpu-baseline > gpurun_out/bench_$L.json 2> gpurun_out/bench_$L.err || (tail -30 gpurun_out/bench_$L.err; exit 1)
 done
 python - <<'PY'
