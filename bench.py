@@ -95,10 +95,13 @@ KERNEL_NAMES = {16: "k_rowgemm / k_rowgemm_db (fp32 MFMA row GEMM)", 17: "k_rowg
                 98: "k_relgcn_layer_bwd"}
 CLASS_NAMES = {1: "row GEMMs", 2: "weight-gradient GEMMs", 3: "gathers", 4: "co-attention pair kernels",
                5: "fused step / layer forward", 6: "fused step / layer backward"}
-# rocprofv3 kernel names of the keys above (profiles/*_pmc_hbm_traffic.json), {D} = hidden width
-PMC_NAMES = {32: "k_wgrad_lds<false>", 33: "k_wgrad_lds<true>", 36: "k_wgrad_lds_multi<0>", 37: "k_wgrad_lds_multi<1>", 80: "k_ggnn_step_fwd<{D}, false>",
-             81: "k_ggnn_step_fwd<{D}, true>", 96: "k_ggnn_step_bwd<{D}, false>", 97: "k_ggnn_step_bwd<{D}, true>",
-             82: "k_relgcn_layer_fwd<{D}>", 98: "k_relgcn_layer_bwd<{D}>", 17: "k_rowgemm_multi", 18: "k_readout_tile_fwd<{D}, true>"}
+# rocprofv3 kernel-name PREFIXES of the keys above (profiles/*_pmc_hbm_traffic.json), {D} = hidden width: the template
+# arguments behind the prefix differ with the tile layout (whole tiles / tile table) and, for the row GEMM, with its epilogue;
+# a key's traffic is the launch-weighted mean over the profile's kernels that carry the prefix
+PMC_NAMES = {16: ("k_rowgemm<", "k_rowgemm_db<", "k_rowgemm_lds<"), 32: ("k_wgrad_lds<false>",), 33: ("k_wgrad_lds<true>",),
+             36: ("k_wgrad_lds_multi<0>",), 37: ("k_wgrad_lds_multi<1>",), 80: ("k_ggnn_step_fwd<{D}, false",),
+             81: ("k_ggnn_step_fwd<{D}, true",), 96: ("k_ggnn_step_bwd<{D}, false",), 97: ("k_ggnn_step_bwd<{D}, true",),
+             82: ("k_relgcn_layer_fwd<{D}",), 98: ("k_relgcn_layer_bwd<{D}",), 17: ("k_rowgemm_multi",), 18: ("k_readout_tile_fwd<{D}",)}
 
 
 def algorithmic_flops_per_pair(cfg, n_pair: float):
@@ -384,11 +387,15 @@ def main():
                     pmc = json.load(open(path))
                 except (OSError, ValueError):
                     continue
-                name = PMC_NAMES.get(top, "").replace("{D}", str(self.cfg["d"]))
-                if pmc.get("_bmp_version") == L.bmp_version() and pmc.get("_config", "c2") == self.name and name in pmc:
+                pre = tuple(x.replace("{D}", str(self.cfg["d"])) for x in PMC_NAMES.get(top, ()))
+                hits = [v for k_, v in pmc.items() if isinstance(v, dict) and pre and k_.startswith(pre)
+                        and "FETCH_SIZE_per_launch" in v and "WRITE_SIZE_per_launch" in v]
+                if pmc.get("_bmp_version") == L.bmp_version() and pmc.get("_config", "c2") == self.name and hits:
                     # counters are in KiB; gfx950 tallies a 16-byte-per-lane streaming read at half its bytes
                     # (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE is doubled, WRITE_SIZE taken as is
-                    traffic = round((2.0 * pmc[name]["FETCH_SIZE_per_launch"] + pmc[name]["WRITE_SIZE_per_launch"]) * 1024)
+                    nl = sum(v["launches"] for v in hits)
+                    traffic = round(sum((2.0 * v["FETCH_SIZE_per_launch"] + v["WRITE_SIZE_per_launch"]) * v["launches"] for v in hits)
+                                    / max(nl, 1) * 1024)
                     break
             return dict(bound="mfma", achieved=k_e["achieved"], peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=k_e["frac"],
                         traffic=traffic, **{k: v for k, v in k_e.items() if k not in ("achieved", "frac")}, kernel_class=c_e,

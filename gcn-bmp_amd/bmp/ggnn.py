@@ -3,8 +3,12 @@
 Mirrors ``models.ggnn.GGNN`` (models/ggnn.py:19-654) and ``models.ggnn_att.GGNN``
 (models/ggnn_att.py:39-664, which adds ``self.atoms`` / ``get_atom_array()``) on the default
 path: message_function='matrix_multiply', readout_function='graph_level', no attention, no
-layer aggregator, no context BiLSTM, no batch normalisation, no dropout.  Any other option
+layer aggregator, no context BiLSTM, no batch normalisation.  Any other option
 raises NotImplementedError (they are research ablations outside SURVEY.md section 8).
+
+``dropout_rate`` (models/ggnn.py:626-627): identity under ``eval()``; in training the zero-padded positions of a molecule
+are ONE row of the packed layout and share one mask, where the reference draws a mask per padded position -- same
+expectation, not the same random process; the float-feature input form keeps every position a row of its own.
 
 Parameter names and shapes follow the reference link tree (embed.W, message_layers.{i}.W/b,
 update_layer.{W_r,W_z,W,U_r,U_z,U}.W/b, i_layers.{k}.W/b, j_layers.{k}.W/b) so a Chainer
