@@ -230,11 +230,13 @@ def main():
     from bmp import synth, packed, _lib, enclayout
     from bmp.predictor import build_pair_predictor
     # Layout the encoder works on, per leg (BMP_BENCH_LAYOUT=encoder|instance forces one everywhere).  Measured on MI355X
-    # (DESIGN.md 3a''): the encoder layout's balanced tile heights make the fused kernels 4-8 % shorter, the two index launches
-    # and the second host plan cost about as much at 1024 pairs on c2 (352 k vs 354 k pairs/s), c3 gains 1.7 %, the
-    # 32-pair batch 14 % (its tiles spread over four times as many CUs); de-duplication always uses it.
+    # (DESIGN.md 3a''): the encoder layout's balanced tile heights make the fused kernels 4-8 % shorter; its two index launches
+    # and its second host plan cost about as much at 1024 pairs on c2 (352 k vs 354 k pairs/s resident); c3 gains 1.7 %
+    # resident but its 1.47 ms step then waits for the host in the end-to-end leg (0.79 of resident instead of 0.97); the
+    # 32-pair batch gains 14 % (its tiles spread over four times as many CUs).  So: per-instance batches for the 1024-pair
+    # legs, the encoder layout for the 32-pair leg and -- always -- for de-duplication.
     LAYOUT = os.environ.get("BMP_BENCH_LAYOUT", "auto")
-    AUTO = {"c2": "instance", "c3": "encoder", "c4": "instance"}
+    AUTO = {"c2": "instance", "c3": "instance", "c4": "instance"}
     from bmp.dp import FlatAdam
     L = _lib.lib()
 
@@ -492,13 +494,19 @@ def main():
             env.train_step(*dds[i % nd])
         dt_d, _ = timed(n_d, lambda i: env.train_step(*dds[(4 + i) % nd]))
         v_d = gb * n_d / dt_d
+        for i in range(4):
+            opt.functional_predict(dds[i % nd][0])
+        dt_pd, _ = timed(n_d, lambda i: opt.functional_predict(dds[(4 + i) % nd][0]))
         dedup = dict(value=round(v_d, 1), unit="pairs/s", steps=n_d, ms_per_step=round(1e3 * dt_d / n_d, 3),
+                     predict_value=round(gb * n_d / dt_pd, 1), predict_ms_per_step=round(1e3 * dt_pd / n_d, 3),
                      distinct_per_step=round(float(np.mean([d_.n_encoded for d_, _ in dds])), 1), instances_per_step=2 * PAIRS_PER_GPU,
                      rows_encoded_per_step=round(float(np.mean([d_.pb_enc.n_rows for d_, _ in dds]))),
                      speedup=round(v_d / value, 3),
                      what="every DISTINCT molecule of a step encoded once (bmp/enclayout.py, dedup=True), co-attention, MLP, loss, backward and Adam as "
                           "in `value`; same pairs, same result up to float32 summation order.  `value`, `roofline` and `whole_step` "
-                          "are per-instance figures and do not include this")
+                          "are per-instance figures and do not include this.  predict_value: the forward-only leg the same way "
+                          "(the reference's evaluators run predict over the train and validation sets every epoch, "
+                          "train_ddi_modify.py:305-372)")
         del dds
 
     # ---- roofline leg: HIP events around every launch (all classes), same workload, rank 0 -------------------

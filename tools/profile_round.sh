@@ -1,5 +1,8 @@
+# Round-3 profiles: kernel stats (one stream + overlapped), PMC passes (HBM traffic for c2 / c3 / c4, SQ for c2 / c3), bench lines.
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/profile_round.sh'   -> gpurun_out/r03_* (copy into profiles/)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=r03
 B="python bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 4"
 # kernel stats with every launch whole and in line on one stream (BMP_ONE_STREAM=1): a kernel's duration is its own.  In the
 # default run the weight-gradient launches share the CUs with the backward chain (low-priority side stream), the forward
@@ -7,23 +10,30 @@ B="python bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 4"
 export BMP_ONE_STREAM=1
 for c in c2 c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$c -- $B --config $c > gpurun_out/ks_$c.log 2>&1
-  python tools/summarize_prof.py gpurun_out/ks_$c gpurun_out/r02_${c}_kernel_stats.csv 34 > /dev/null
+  python tools/summarize_prof.py gpurun_out/ks_$c gpurun_out/${R}_${c}_kernel_stats.csv 34 > /dev/null
   rm -rf gpurun_out/ks_$c
 done
-# counter passes: whole launches too (per-launch counters next to the roofline leg's per-launch figures)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- $B > gpurun_out/pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- $B > gpurun_out/pmc_w.log 2>&1
-python tools/summarize_pmc.py gpurun_out/r02_c2_pmc_hbm_traffic.json gpurun_out/pmc_f gpurun_out/pmc_w > /dev/null
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d gpurun_out/pmc_s -- $B > gpurun_out/pmc_s.log 2>&1
-python tools/summarize_pmc.py gpurun_out/r02_c2_pmc_sq.json gpurun_out/pmc_s > /dev/null
-rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_s
+# counter passes: whole launches too (per-launch counters next to the roofline leg's per-launch figures); FETCH and WRITE in
+# separate passes, as MI355X_MICROARCH.md prescribes
+for c in c2 c3 c4; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -- $B --config $c > gpurun_out/pmc_f_$c.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -- $B --config $c > gpurun_out/pmc_w_$c.log 2>&1
+  BMP_PROFILE_CONFIG=$c python tools/summarize_pmc.py gpurun_out/${R}_${c}_pmc_hbm_traffic.json gpurun_out/pmc_f gpurun_out/pmc_w > /dev/null
+  rm -rf gpurun_out/pmc_f gpurun_out/pmc_w
+done
+for c in c2 c3; do
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d gpurun_out/pmc_s -- $B --config $c > gpurun_out/pmc_s_$c.log 2>&1
+  BMP_PROFILE_CONFIG=$c python tools/summarize_pmc.py gpurun_out/${R}_${c}_pmc_sq.json gpurun_out/pmc_s > /dev/null
+  rm -rf gpurun_out/pmc_s
+done
 unset BMP_ONE_STREAM
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_o -- $B --config c2 > gpurun_out/ks_o.log 2>&1
-python tools/summarize_prof.py gpurun_out/ks_o gpurun_out/r02_c2_kernel_stats_overlapped.csv 34 > /dev/null
+python tools/summarize_prof.py gpurun_out/ks_o gpurun_out/${R}_c2_kernel_stats_overlapped.csv 34 > /dev/null
 rm -rf gpurun_out/ks_o
-ls gpurun_out | grep r02_
-cp gpurun_out/r02_c2_pmc_hbm_traffic.json profiles/      # the bench quotes `traffic` from the file of ITS library version
-for c in c2 c3 c4; do
-  python bench.py --config $c > gpurun_out/r02_bench_$c.json 2> gpurun_out/r02_bench_$c.err
+ls gpurun_out | grep ${R}_
+cp gpurun_out/${R}_c?_pmc_hbm_traffic.json profiles/      # the bench quotes `traffic` from the files of ITS library version
+python bench.py > gpurun_out/${R}_bench_c2.json 2> gpurun_out/${R}_bench_c2.err
+for c in c3 c4; do
+  python bench.py --config $c --no-cpu-baseline > gpurun_out/${R}_bench_$c.json 2> gpurun_out/${R}_bench_$c.err
 done
-ls gpurun_out | grep r02_bench
+ls gpurun_out | grep ${R}_bench
