@@ -687,13 +687,15 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         for (int j = tid; j < n1; j += NT) {
             float dv1 = 0.f;
             for (int i = 0; i < n2; ++i) dv1 += L.dSs[i * ldc + j];
-            a.dZ1[(size_t)(r1 + j) * ZC + o + H] = dv1;
+            { float* dzr = a.dZ1 + (size_t)(r1 + j) * ZC; dzr[o + H] = dv1;
+              for (int c = o + H + 1; c < ZC; ++c) dzr[c] = 0.f; }      // the row's padding columns: the same cache line
         }
         float mine = 0.f;
         for (int i = tid; i < n2; i += NT) {
             float dv2 = 0.f;
             for (int j = 0; j < n1; ++j) dv2 += L.dSs[i * ldc + j];
-            a.dZ2[(size_t)(r2 + i) * ZC + o + H] = dv2;
+            { float* dzr = a.dZ2 + (size_t)(r2 + i) * ZC; dzr[o + H] = dv2;
+              for (int c = o + H + 1; c < ZC; ++c) dzr[c] = 0.f; }      // the row's padding columns: the same cache line
             mine += dv2;
         }
         const float tot = wave_sum(mine);
@@ -710,14 +712,16 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
         if (j < n1) {
             float dv1 = 0.f;
             for (int i = 0; i < n2; ++i) dv1 += L.dSs[i * ldc + j];
-            a.dZ1[(size_t)(r1 + j) * ZC + o + H] = dv1;
+            { float* dzr = a.dZ1 + (size_t)(r1 + j) * ZC; dzr[o + H] = dv1;
+              for (int c = o + H + 1; c < ZC; ++c) dzr[c] = 0.f; }      // the row's padding columns: the same cache line
         }
     } else {
         const int i = tid - CO_MAXN;
         float dv2 = 0.f;
         if (i < n2) {
             for (int j = 0; j < n1; ++j) dv2 += L.dSs[i * ldc + j];
-            a.dZ2[(size_t)(r2 + i) * ZC + o + H] = dv2;
+            { float* dzr = a.dZ2 + (size_t)(r2 + i) * ZC; dzr[o + H] = dv2;
+              for (int c = o + H + 1; c < ZC; ++c) dzr[c] = 0.f; }      // the row's padding columns: the same cache line
         }
         const float tot = wave_sum(dv2);
         if (lane == 0 && wave < 4) L.dots1[wave - 2] = tot;
@@ -975,7 +979,9 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     // molecule, so with the row -> molecule maps of the packed batches (-1: no molecule) only those rows are cleared
     // (a few hundred rows instead of 125 MB of fills); without the maps everything is
     if (row_mol1 && row_mol2) {
-        hipLaunchKernelGGL(k_zero_dead_rows, dim3((N1 + N2 + 255) / 256), dim3(256), 0, st, row_mol1, row_mol2, N1, N2, d, ZC, o + H + 1, dX1,
+        // (the padding columns [o + H + 1, ZC) of the LIVE rows are cleared by the pair kernels next to the dv column they write;
+        //  one thread per row doing it here was 58 k partial cache lines and 23 us)
+        hipLaunchKernelGGL(k_zero_dead_rows, dim3((N1 + N2 + 255) / 256), dim3(256), 0, st, row_mol1, row_mol2, N1, N2, d, ZC, ZC, dX1,
                            dZ1, dQ2, dZ2);
         BMP_LAUNCH_CHECK();
     } else {
