@@ -403,12 +403,19 @@ class GGNN(nn.Module):
         infer = not torch.is_grad_enabled()      # predict under no-backprop: nothing is kept for a backward
         bufs = [Fn.step_buffers(h.shape[0], self.hidden_dim, h.device, infer) for _ in range(self.n_layers)]
         Fn.fork_parts(state, pb)
+        per_step = []
         for step, (li, mode) in enumerate(self._step_groups()):
             W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
                      b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])
             g = f"g{li}_{mode}"
             Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
-            h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, step == 0, bufs[step])
+            per_step.append((W, Gs, g, step == 0))
+        if Fn.tsteps_supported(self.hidden_dim, self.n_layers):
+            # all steps of a tile in one launch per chain, the atom states resident in LDS (models/ggnn.py:616-623)
+            h = Fn.PTStepsFn.apply(h, pb, per_step, state, bufs)
+        else:
+            for step, (W, Gs, g, first) in enumerate(per_step):
+                h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, first, bufs[step])
         Fn._join_parts(state)                 # the steps ran as two chains of tiles: whole arrays are read from here on
         return h, h0
 

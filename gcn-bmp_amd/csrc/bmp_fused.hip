@@ -12,10 +12,12 @@
 //   D = 128: 2 x 4 waves, RB = 2;  D = 64: 4 x 2 waves, RB = 1.
 //   dense work: v_mfma_f32_32x32x2_f32 (exact f32); K order per lane: four consecutive k per 16-B read.
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 #include "bmp_kernels.h"
 
 #define FZ_R 128
+#define FZ_TMAX 8         // propagation steps of one multi-step forward launch
 
 struct StepArgs {
     // graph
@@ -41,6 +43,10 @@ struct StepArgs {
     const float* Uc;                // [D x D]   (= UcT^T, reference layout)
     float* dh;                      // [N x D]
     float* gda;                     // [N x 7D]: G (4D: gathered dm per bond type) | da_r | da_z | da_c
+    // all T steps of a tile in one forward launch (k_ggnn_step_fwd<.., TS = true>): step t's weights and outputs
+    int T;
+    const float* ts_WT[FZ_TMAX]; const float* ts_bE[FZ_TMAX]; const float* ts_AT[FZ_TMAX]; const float* ts_b[FZ_TMAX];
+    float* ts_m[FZ_TMAX]; float* ts_rz[FZ_TMAX]; float* ts_c[FZ_TMAX]; float* ts_hout[FZ_TMAX];
 };
 
 // acc[nb][rb] += A(rows of this wave, K) . B_nb(K, 32 cols)   with A in LDS, B streamed from global.
@@ -279,7 +285,7 @@ __device__ __forceinline__ int fz_live(int nblk, int wr) {
 
 // SAVE == false: forward-only evaluation (m, r|z, c are not kept).  The epilogues' arithmetic is written with explicit fused
 // multiply-adds so that both instances round alike: predict's logits are bit for bit the training forward's.
-template <int D, bool FIRST, bool VAR, bool SAVE>
+template <int D, bool FIRST, bool VAR, bool SAVE, bool TS>
 __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -295,7 +301,6 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int grp = w >> 2;                  // half of the tile this wave works on in every phase
     GrpSync gs{sy + grp, 0};
-    int tmask = 0;
     if (tid < FZ_NSYNC) sy[tid] = 0;
     if (grp == 0) __builtin_amdgcn_s_setprio(2);
     const int wc = w % NCB, wr = w / NCB;
@@ -323,110 +328,136 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     __syncthreads();
     if (!grp_live) return;                   // a short tile: this half has no rows
 
-    // ---- message: m = sum_e AGG_e . W_e + wdeg_e * b_e   (models/ggnn.py:223-242) ----
-    f32x16 acc_m[1][RB];
-    zero_acc(acc_m[0]);
-    for (int e = 0; e < 4; ++e) {
-        const float* const Bp[1] = {a.WT + (size_t)(e * D + 4 * hi) * D + 4 * col};
-        const int ldw[1] = {D};
-        BPre<1> pre;
-        tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
-        float wd;
-        FZ_GATHER(Hs, As, e, &wd);
-        if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
-        // bond types present in this half of the tile: known after the first pass (it walks every entry)
-        if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        grp_sync(gs);
-        const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
-        FZ_GSYNC();
-    }
-    // first B fragments of the h-part of the gates: requested now, used after the m epilogue and its barrier
-    constexpr int NG = FIRST ? 2 : 3;                     // gates computed: first call after reset z and c only
-    int ldwg[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) ldwg[g] = 3 * D;
-    const float* const base_h = a.AT + (size_t)(4 * hi) * 3 * D + 4 * col + (FIRST ? 4 * D : 0);
-    const float* const base_m = a.AT + (size_t)(D + 4 * hi) * 3 * D + 4 * col + (FIRST ? 4 * D : 0);
-    const float* Bh[NG]; const float* Bm[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) { Bh[g] = base_h + 4 * D * g; Bm[g] = base_m + 4 * D * g; }
-    BPre<NG> pre_h;
-    tile_b_prefetch<NG>(pre_h, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot);
-    // m -> LDS (A operand of the gates) and HBM (saved for the backward)
-    {
-        const AccBuf mo = acc_buf<D>(a.m, row0, lrow, col);
-        float be[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) be[e] = a.bE[e * D + col];
-        FZ_FOR_ACC {
-            const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
-            const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
-            const float v = __builtin_fmaf(wd4[3], be[3], __builtin_fmaf(wd4[2], be[2], __builtin_fmaf(wd4[1], be[1],
-                                           __builtin_fmaf(wd4[0], be[0], acc_m[0][rb][reg]))));
-            Al[LOFF(rb, reg)] = v;
-            if (save) acc_st<D>(mo, rb, reg, v);
+    // one propagation step on the resident tile (Hs): message, gates, h'.  A generic lambda so that the first call after reset
+    // (no r gate, no U term: FST) and the later calls are two instances of the same text inside ONE kernel (TS: all T steps of
+    // a tile in one launch; models/ggnn.py:616-623 -- a tile's molecules are self-contained across steps).
+    auto step = [&](auto first_c, const float* WTs, const float* bEs, const float* ATs, const float* bvs, float* om, float* orz,
+                    float* oc, float* oh, bool more) {
+        constexpr bool FST = decltype(first_c)::value;
+        int tmask = 0;
+        // ---- message: m = sum_e AGG_e . W_e + wdeg_e * b_e   (models/ggnn.py:223-242) ----
+        f32x16 acc_m[1][RB];
+        zero_acc(acc_m[0]);
+        for (int e = 0; e < 4; ++e) {
+            const float* const Bp[1] = {WTs + (size_t)(e * D + 4 * hi) * D + 4 * col};
+            const int ldw[1] = {D};
+            BPre<1> pre;
+            tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
+            float wd;
+            FZ_GATHER(Hs, As, e, &wd);
+            if ((tid & 3) == 0) wds[(tid >> 2) * 4 + e] = wd;
+            // bond types present in this half of the tile: known after the first pass (it walks every entry)
+            if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            grp_sync(gs);
+            const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
+            if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
+            FZ_GSYNC();
         }
-    }
-    FZ_GSYNC();
-
-    // ---- gates: [r | z | c~] = [h, m] . AT   (chainer StatefulGRU) ----
-    f32x16 acc_g[3][RB];
-    zero_acc(acc_g[0]); zero_acc(acc_g[1]); zero_acc(acc_g[2]);
-    {
-        f32x16 gg[NG][RB];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) zero_acc(gg[g]);
-        BPre<NG> pre_m;                                   // in flight under the h-part
-        tile_b_prefetch<NG>(pre_m, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot);
-        tile_mma_n<VAR, NG, RB>(nrb, gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h);
-        tile_mma_n<VAR, NG, RB>(nrb, gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m);
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc_g[g + (FIRST ? 1 : 0)][rb] = gg[g][rb];
-    }
-    const float br = a.b[col], bz = a.b[D + col], bcn = a.b[2 * D + col];
-    {   // r, z in place; save them
-        const AccBuf rzo = acc_buf<2 * D>(a.rz, row0, lrow, col);
-        FZ_FOR_ACC {
-            const float zv = bmp_sigmoid(acc_g[1][rb][reg] + bz);
-            acc_g[1][rb][reg] = zv;
-            if (save) acc_st<2 * D>(rzo, rb, reg, zv, D);
-            if (!FIRST) {
-                const float rv = bmp_sigmoid(acc_g[0][rb][reg] + br);
-                acc_g[0][rb][reg] = rv;
-                if (save) acc_st<2 * D>(rzo, rb, reg, rv, 0);
+        // first B fragments of the h-part of the gates: requested now, used after the m epilogue and its barrier
+        constexpr int NG = FST ? 2 : 3;                     // gates computed: first call after reset z and c only
+        int ldwg[NG];
+    #pragma unroll
+        for (int g = 0; g < NG; ++g) ldwg[g] = 3 * D;
+        const float* const base_h = ATs + (size_t)(4 * hi) * 3 * D + 4 * col + (FST ? 4 * D : 0);
+        const float* const base_m = ATs + (size_t)(D + 4 * hi) * 3 * D + 4 * col + (FST ? 4 * D : 0);
+        const float* Bh[NG]; const float* Bm[NG];
+    #pragma unroll
+        for (int g = 0; g < NG; ++g) { Bh[g] = base_h + 4 * D * g; Bm[g] = base_m + 4 * D * g; }
+        BPre<NG> pre_h;
+        tile_b_prefetch<NG>(pre_h, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot);
+        // m -> LDS (A operand of the gates) and HBM (saved for the backward)
+        {
+            const AccBuf mo = acc_buf<D>(om, row0, lrow, col);
+            float be[4];
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) be[e] = bEs[e * D + col];
+            FZ_FOR_ACC {
+                const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+                const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
+                const float v = __builtin_fmaf(wd4[3], be[3], __builtin_fmaf(wd4[2], be[2], __builtin_fmaf(wd4[1], be[1],
+                                               __builtin_fmaf(wd4[0], be[0], acc_m[0][rb][reg]))));
+                Al[LOFF(rb, reg)] = v;
+                if (save) acc_st<D>(mo, rb, reg, v);
             }
         }
-    }
-    if (!FIRST) {
-        const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
-        const int ldu[1] = {D};
-        BPre<1> pre_u;
-        tile_b_prefetch<1>(pre_u, Bu, ldu, D, rot);
-        FZ_GSYNC();                          // every wave of this half is done reading M
-        FZ_FOR_ACC { Al[LOFF(rb, reg)] = acc_g[0][rb][reg] * Hl[LOFF(rb, reg)]; }      // r * h
         FZ_GSYNC();
-        f32x16 gc[1][RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
-        tile_mma_n<VAR, 1, RB>(nrb, gc, Aw, LD, Bu, ldu, D, rot, &pre_u);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
-    }
-    // ---- h' = z*c + (1-z)*h  (first call: z*c) ----
-    {
-        const AccBuf co = acc_buf<D>(a.c, row0, lrow, col);
-        const AccBuf ho = acc_buf<D>(a.hout, row0, lrow, col);
-        FZ_FOR_ACC {
-            const float cv = bmp_tanh(acc_g[2][rb][reg] + bcn);
-            const float zv = acc_g[1][rb][reg];
-            float hn = zv * cv;
-            if (!FIRST) hn = __builtin_fmaf(1.f - zv, Hl[LOFF(rb, reg)], hn);
-            if (save) acc_st<D>(co, rb, reg, cv);
-            acc_st<D>(ho, rb, reg, hn);
+
+        // ---- gates: [r | z | c~] = [h, m] . AT   (chainer StatefulGRU) ----
+        f32x16 acc_g[3][RB];
+        zero_acc(acc_g[0]); zero_acc(acc_g[1]); zero_acc(acc_g[2]);
+        {
+            f32x16 gg[NG][RB];
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) zero_acc(gg[g]);
+            BPre<NG> pre_m;                                   // in flight under the h-part
+            tile_b_prefetch<NG>(pre_m, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot);
+            tile_mma_n<VAR, NG, RB>(nrb, gg, Hw, LD, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot, &pre_h);
+            tile_mma_n<VAR, NG, RB>(nrb, gg, Aw, LD, (const float* const (&)[NG])Bm, (const int (&)[NG])ldwg, D, rot, &pre_m);
+    #pragma unroll
+            for (int g = 0; g < NG; ++g)
+    #pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc_g[g + (FST ? 1 : 0)][rb] = gg[g][rb];
         }
+        const float br = bvs[col], bz = bvs[D + col], bcn = bvs[2 * D + col];
+        {   // r, z in place; save them
+            const AccBuf rzo = acc_buf<2 * D>(orz, row0, lrow, col);
+            FZ_FOR_ACC {
+                const float zv = bmp_sigmoid(acc_g[1][rb][reg] + bz);
+                acc_g[1][rb][reg] = zv;
+                if (save) acc_st<2 * D>(rzo, rb, reg, zv, D);
+                if (!FST) {
+                    const float rv = bmp_sigmoid(acc_g[0][rb][reg] + br);
+                    acc_g[0][rb][reg] = rv;
+                    if (save) acc_st<2 * D>(rzo, rb, reg, rv, 0);
+                }
+            }
+        }
+        if (!FST) {
+            const float* const Bu[1] = {a.UcT + (size_t)(4 * hi) * D + 4 * col};
+            const int ldu[1] = {D};
+            BPre<1> pre_u;
+            tile_b_prefetch<1>(pre_u, Bu, ldu, D, rot);
+            FZ_GSYNC();                          // every wave of this half is done reading M
+            FZ_FOR_ACC { Al[LOFF(rb, reg)] = acc_g[0][rb][reg] * Hl[LOFF(rb, reg)]; }      // r * h
+            FZ_GSYNC();
+            f32x16 gc[1][RB];
+    #pragma unroll
+            for (int rb = 0; rb < RB; ++rb) gc[0][rb] = acc_g[2][rb];
+            tile_mma_n<VAR, 1, RB>(nrb, gc, Aw, LD, Bu, ldu, D, rot, &pre_u);
+    #pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc_g[2][rb] = gc[0][rb];
+        }
+        // ---- h' = z*c + (1-z)*h  (first call: z*c) ----
+        {
+            const AccBuf co = acc_buf<D>(oc, row0, lrow, col);
+            const AccBuf ho = acc_buf<D>(oh, row0, lrow, col);
+            FZ_FOR_ACC {
+                const float cv = bmp_tanh(acc_g[2][rb][reg] + bcn);
+                const float zv = acc_g[1][rb][reg];
+                float hn = zv * cv;
+                if (!FST) hn = __builtin_fmaf(1.f - zv, Hl[LOFF(rb, reg)], hn);
+                if (save) acc_st<D>(co, rb, reg, cv);
+                acc_st<D>(ho, rb, reg, hn);
+                if (TS) acc_g[2][rb][reg] = hn;          // stays in registers for the write-back into the resident tile
+            }
+        }
+        if (TS && more) {
+            // the next step reads the WHOLE tile (a neighbour may sit in the other half): every wave of the workgroup is done
+            // reading this step's h before anyone overwrites it, and sees the new one before it gathers from it
+            __syncthreads();
+            FZ_FOR_ACC { Hl[LOFF(rb, reg)] = acc_g[2][rb][reg]; }
+            __syncthreads();
+        }
+    };
+    if constexpr (!TS) {
+        step(std::integral_constant<bool, FIRST>{}, a.WT, a.bE, a.AT, a.b, a.m, a.rz, a.c, a.hout, false);
+    } else {
+        // step 0 is the GRU's first call after reset iff FIRST; the steps behind it are later calls
+        step(std::integral_constant<bool, FIRST>{}, a.ts_WT[0], a.ts_bE[0], a.ts_AT[0], a.ts_b[0], a.ts_m[0], a.ts_rz[0], a.ts_c[0],
+             a.ts_hout[0], a.T > 1);
+        for (int t = 1; t < a.T; ++t)
+            step(std::integral_constant<bool, false>{}, a.ts_WT[t], a.ts_bE[t], a.ts_AT[t], a.ts_b[t], a.ts_m[t], a.ts_rz[t], a.ts_c[t],
+                 a.ts_hout[t], t + 1 < a.T);
     }
 }
 
@@ -921,21 +952,32 @@ extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
 // `rows`: rows the launch works on (flop / byte accounting of the roofline leg: with a tile table the live rows, passed by the caller).
 template <int D, bool FIRST, bool VAR>
 static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, double rows, hipStream_t st) {
-    const int kind = bwd ? 2 : (a.m != nullptr ? 0 : 1);      // forward keeping m / rz / c, forward-only evaluation, backward
+    // kind: 0 forward keeping m / rz / c, 1 forward-only evaluation, 2 backward, 3 / 4: all T steps in one forward launch
+    const bool ts = !bwd && a.T > 0;
+    const bool keep = ts ? a.ts_m[0] != nullptr : a.m != nullptr;
+    const int kind = bwd ? 2 : (ts ? (keep ? 3 : 4) : (keep ? 0 : 1));
     const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, VAR>
-                         : (kind == 0 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true> : (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false>);
-    static bool attr_set[3] = {false, false, false};      // per template instance, per kind: set once, not per launch
+                   : kind == 0 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true, false>
+                   : kind == 1 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false, false>
+                   : kind == 3 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true, true>
+                               : (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false, true>;
+    static bool attr_set[5] = {false, false, false, false, false};      // per template instance, per kind: set once, not per launch
     if (!attr_set[kind]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
         if (e != hipSuccess) return (int)e;
         attr_set[kind] = true;
     }
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
-    BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * (4.0 + gates) * D * D,
-                      4.0 * rows * D * (bwd ? 13.0 : 6.0), st, FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER);
+    // (all T steps in one launch: the first step's work + T - 1 later steps')
+    const double macs = ts ? (4.0 + gates) + (a.T - 1) * 11.0 : (4.0 + gates);
+    BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * macs * D * D,
+                      4.0 * rows * D * (bwd ? 13.0 : (ts ? 1.0 + 5.0 * a.T : 6.0)), st,
+                      ts ? BMP_KID_GGNN_TSTEPS : (FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER));
     if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else if (kind == 0) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else if (kind == 0) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else if (kind == 1) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else if (kind == 3) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
 }
@@ -961,6 +1003,34 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, 
     BMP_REQUIRE((mt_row0 != nullptr) == (mt_nblk != nullptr));
     a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
+    return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
+}
+
+// ALL T propagation steps of every tile in ONE forward launch (models/ggnn.py:616-623: a tile's
+// molecules are self-contained across steps): the tile's atom states stay in LDS from step to step, every step writes the m,
+// r|z, c and h' the per-step backward reads (or only h' of the last step when the m / rz / c arrays are NULL: forward-only
+// evaluation).  WT, bE, AT, b, m, rz, c, hout: HOST arrays of T device pointers (step t's message weights and GRU operands --
+// the same pointers for tied layers; step 0 takes the first-call GRU form when first != 0, the others the later-call form).
+// Bit for bit the per-step launches' results.
+extern "C" int bmp_ggnn_steps_fwd(const float* h, int tile0, int n_tiles, int d, int T, int first, const int* csr_ptr,
+                                  const int* csr_col, const float* csr_val, const float* const* WT, const float* const* bE,
+                                  const float* const* AT, const float* UcT, const float* const* b, float* const* m,
+                                  float* const* rz, float* const* c, float* const* hout, const int* mt_row0, const int* mt_nblk,
+                                  int mt_rows, hipStream_t st) {
+    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d) && T >= 1 && T <= FZ_TMAX);
+    BMP_REQUIRE(WT && bE && AT && b && hout && UcT && (mt_row0 != nullptr) == (mt_nblk != nullptr));
+    StepArgs a; memset(&a, 0, sizeof(a));
+    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
+    a.h = h; a.UcT = UcT; a.T = T;
+    const bool keep = m != nullptr && m[0] != nullptr;
+    for (int t = 0; t < T; ++t) {
+        BMP_REQUIRE(WT[t] && bE[t] && AT[t] && b[t] && hout[t]);
+        a.ts_WT[t] = WT[t]; a.ts_bE[t] = bE[t]; a.ts_AT[t] = AT[t]; a.ts_b[t] = b[t]; a.ts_hout[t] = hout[t];
+        if (keep) {
+            BMP_REQUIRE(m[t] && rz && rz[t] && c && c[t]);
+            a.ts_m[t] = m[t]; a.ts_rz[t] = rz[t]; a.ts_c[t] = c[t];
+        }
+    }
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
 
