@@ -8,6 +8,9 @@ hot path with chainer.training (train_binary.py:530-665, train_ddi_modify.py:280
 * ``EarlyStopping`` = triggers.EarlyStoppingTrigger(monitor='validation/main/loss', patients=50,
   max_trigger=(500, 'epoch')) (train_binary.py:558);
 * ``augment_pairs``: the pair swap of augment_dataset (train_binary.py:285-294) on index arrays;
+* ``PairBatches``: SerialIterator + the converter concat_mols (train_binary.py:520-528, 551) over a pair list and a drug store
+  resident in HBM: every batch collated on the device, in the per-instance layout or in the encoder layout (optionally with
+  every distinct molecule of the batch encoded once), this rank's share of each global batch;
 * ``fit``: StandardUpdater + the extensions above as one loop over packed batches, log entries named as the
   reference's PrintReport columns (train_binary.py:650-658).
 
@@ -95,14 +98,18 @@ def classification_metrics(prob: np.ndarray, t: np.ndarray, ignore_label: Option
 
 
 # ---- evaluation / schedule / stopping -------------------------------------------------------------------------------
-def evaluate(predictor, batches: Iterable, lossfun: Optional[Callable] = None, ignore_label: int = -1) -> Dict[str, float]:
-    """``batches`` yields (inputs, labels) with inputs a packed batch or the reference's tuple of four arrays."""
+def evaluate(predictor, batches: Iterable, lossfun: Optional[Callable] = None, ignore_label: int = -1, opt=None) -> Dict[str, float]:
+    """``batches`` yields (inputs, labels) with inputs a packed batch or the reference's tuple of four arrays.  With ``opt``
+    (bmp.dp.FlatAdam) the logits come from ``opt.functional_predict``: the planned forward-only path on the flat buffer."""
     ys, ts, losses, n = [], [], 0.0, 0
     was_training = predictor.training
     predictor.eval()
     with torch.no_grad():
         for inputs, t in batches:
-            y = predictor(*inputs) if isinstance(inputs, (tuple, list)) else predictor(inputs)
+            if opt is not None:
+                y = opt.functional_predict(*inputs)[0] if isinstance(inputs, (tuple, list)) else opt.functional_predict(inputs)[0]
+            else:
+                y = predictor(*inputs) if isinstance(inputs, (tuple, list)) else predictor(inputs)
             if lossfun is not None:
                 losses += float(lossfun(y, t)) * len(t); n += len(t)
             ys.append(torch.sigmoid(y).float().cpu().numpy()); ts.append(torch.as_tensor(t).cpu().numpy())
@@ -151,6 +158,57 @@ def augment_pairs(idx1: np.ndarray, idx2: np.ndarray, label: np.ndarray):
     return np.concatenate((idx1, idx2)), np.concatenate((idx2, idx1)), np.concatenate((label, label))
 
 
+class PairBatches:
+    """The reference's SerialIterator(dataset, batchsize, shuffle=...) + converter concat_mols for one rank: an iterable of
+    (batch, labels on the device), re-collated from the store in HBM on every pass (a new order per pass when ``shuffle``,
+    like SerialIterator's per-epoch permutation; the last batch of a pass is the short remainder, as with repeat=False).
+
+    ``layout`` "instance": bmp.packed.pack_from_store_device.  "encoder": bmp.enclayout.encode_from_store_device (encoder
+    tiles balanced over the CUs); with ``dedup`` every distinct molecule of this rank's share is encoded once and its atom
+    states are copied to the instances -- the same logits and gradients, fewer encoder rows.  With ``world`` > 1 a global
+    batch is ``batch_size * world`` pairs and this rank takes its contiguous share (a remainder smaller than ``world`` is
+    left out, so that no rank steps on an empty batch)."""
+
+    def __init__(self, dstore, idx1: np.ndarray, idx2: np.ndarray, labels: np.ndarray, batch_size: int, shuffle: bool = False,
+                 seed: int = 0, layout: str = "instance", dedup: bool = False, rank: int = 0, world: int = 1):
+        if layout not in ("instance", "encoder"):
+            raise ValueError(f"layout {layout!r}: 'instance' or 'encoder'")
+        if dedup and layout != "encoder":
+            raise ValueError("dedup needs layout='encoder'")
+        if not (len(idx1) == len(idx2) == len(labels)):
+            raise ValueError("idx1, idx2 and labels must have one entry per pair")
+        self.dstore, self.i1, self.i2, self.lab = dstore, np.asarray(idx1), np.asarray(idx2), np.asarray(labels)
+        self.B, self.shuffle, self.seed, self.layout, self.dedup = int(batch_size), shuffle, seed, layout, dedup
+        self.rank, self.world, self.epoch = rank, world, 0
+
+    def __len__(self) -> int:
+        g = self.B * self.world
+        full, rem = divmod(len(self.lab), g)
+        return full + (1 if rem >= self.world else 0)
+
+    def selections(self):
+        """This pass's pair indices, one array per batch of this rank (advances the pass counter)."""
+        n, g = len(self.lab), self.B * self.world
+        order = np.random.RandomState(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        self.epoch += 1
+        for lo in range(0, n, g):
+            sel = order[lo:lo + g]
+            if len(sel) < self.world:
+                break
+            q, r = divmod(len(sel), self.world)          # ranks 0..r-1 take one pair more: no rank is left without pairs
+            a = self.rank * q + min(self.rank, r)
+            yield sel[a:a + q + (1 if self.rank < r else 0)]
+
+    def __iter__(self):
+        from . import enclayout, packed
+        for sel in self.selections():
+            sides, lab = [self.i1[sel], self.i2[sel]], self.lab[sel]
+            if self.layout == "encoder":
+                yield enclayout.encode_from_store_device(self.dstore, sides, labels=lab, dedup=self.dedup)
+            else:
+                yield packed.pack_from_store_device(self.dstore, sides, labels=lab)
+
+
 def fit(model, opt, train_batches: Sequence, valid_batches: Sequence = (), epochs: int = 1,
         shift: Optional[ExponentialShift] = None, stopper: Optional[EarlyStopping] = None, eval_train: bool = False,
         report: Optional[Callable[[Dict[str, float]], None]] = None) -> List[Dict[str, float]]:
@@ -171,11 +229,11 @@ def fit(model, opt, train_batches: Sequence, valid_batches: Sequence = (), epoch
             n += len(t)
         log = {"epoch": epoch, "main/loss": float(tot) / max(n, 1) if tot is not None else float("nan")}
         if eval_train:
-            m = evaluate(model, train_batches)
+            m = evaluate(model, train_batches, opt=opt)
             log.update({"train_acc/main/accuracy": m["accuracy"], "train_roc/main/roc_auc": m["roc_auc"],
                         "train_prc/main/prc_auc": m["prc_auc"], "train_f/main/f1": m["f1"]})
         if len(valid_batches):
-            m = evaluate(model, valid_batches, lossfun=model.loss)
+            m = evaluate(model, valid_batches, lossfun=model.loss, opt=opt)
             log.update({"validation/main/loss": m["loss"], "val_acc/main/accuracy": m["accuracy"],
                         "val_roc/main/roc_auc": m["roc_auc"], "val_prc/main/prc_auc": m["prc_auc"], "val_f/main/f1": m["f1"]})
         log["lr"] = shift(epoch) if shift is not None else opt.alpha

@@ -51,6 +51,57 @@ def test_shift_and_early_stopping_and_augment():
     assert i1.tolist() == [0, 1, 2, 3] and i2.tolist() == [2, 3, 0, 1] and lab.tolist() == [1, 0, 1, 0]
 
 
+@pytest.mark.parametrize("n,B,world", [(100, 16, 1), (100, 16, 4), (67, 8, 3), (9, 4, 4), (3, 4, 4)])
+def test_pair_batches_share_every_global_batch_over_the_ranks(n, B, world):
+    i1 = np.arange(n); lab = np.zeros((n, 1), dtype=np.int32)
+    its = [T.PairBatches(None, i1, i1, lab, B, shuffle=True, seed=5, rank=r, world=world) for r in range(world)]
+    per_rank = [list(it.selections()) for it in its]
+    assert len({len(p) for p in per_rank}) == 1 and len(per_rank[0]) == len(its[0])        # every rank steps equally often
+    seen = np.concatenate([s for p in per_rank for s in p]) if per_rank[0] else np.zeros(0, dtype=np.int64)
+    assert len(set(seen.tolist())) == len(seen) and n - len(seen) < world                  # disjoint, all but < world pairs
+    assert all(len(s) >= 1 for p in per_rank for s in p)
+    for k in range(len(per_rank[0])):                                                      # a global batch = consecutive order
+        got = np.concatenate([per_rank[r][k] for r in range(world)])
+        want = np.random.RandomState(5).permutation(n)[k * B * world:(k + 1) * B * world]
+        assert got.tolist() == want.tolist()
+    second = list(its[0].selections())                                                     # a new order on the next pass
+    assert n < 8 or any(a.tolist() != b.tolist() for a, b in zip(per_rank[0], second))
+    with pytest.raises(ValueError):
+        T.PairBatches(None, i1, i1, lab, B, dedup=True)
+
+
+@pytest.mark.gpu
+def test_fit_from_the_store_in_either_layout_gives_the_same_run():
+    """PairBatches in the per-instance layout, in the encoder layout and with each distinct molecule encoded once: the same
+    losses and validation metrics epoch by epoch (different summation orders only)."""
+    from bmp import packed, synth
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    dev = torch.device("cuda:0")
+    store = synth.make_store(40, seed=3, n_lo=4, n_hi=40, n_mean=16)
+    ds = packed.DeviceMolStore(packed.MolStore(store), dev)
+    rs = np.random.RandomState(1)
+    i1, i2 = rs.randint(0, 40, 320), rs.randint(0, 40, 320)
+    nat = np.array([m.n for m in store])
+    lab = ((nat[i1] + nat[i2]) % 2).astype(np.int32).reshape(-1, 1)
+    runs = {}
+    for name, kw in (("instance", {}), ("encoder", dict(layout="encoder")), ("dedup", dict(layout="encoder", dedup=True))):
+        torch.manual_seed(0)
+        model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=2, attn="nie", head=4).to(dev)
+        opt = FlatAdam(model, alpha=2e-3)
+        tr = T.PairBatches(ds, i1[:256], i2[:256], lab[:256], 48, shuffle=True, seed=2, **kw)
+        va = T.PairBatches(ds, i1[256:], i2[256:], lab[256:], 48, **kw)
+        assert len(tr) == 6 and len(va) == 2
+        runs[name] = T.fit(model, opt, tr, va, epochs=3, eval_train=True)
+    for name in ("encoder", "dedup"):
+        for a, b in zip(runs["instance"], runs[name]):
+            for key in ("main/loss", "validation/main/loss"):
+                assert abs(a[key] - b[key]) <= 2e-4 * abs(a[key]), (name, key, a[key], b[key])
+            for key in ("val_roc/main/roc_auc", "train_roc/main/roc_auc"):
+                assert abs(a[key] - b[key]) <= 5e-3, (name, key, a[key], b[key])
+    assert runs["instance"][-1]["main/loss"] < runs["instance"][0]["main/loss"]
+
+
 @pytest.mark.gpu
 def test_fit_lowers_the_loss_and_reports_reference_columns():
     from bmp import packed, synth
