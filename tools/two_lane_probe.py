@@ -66,9 +66,84 @@ torch.cuda.synchronize()
 A, Bm = lane(), lane()
 cur = torch.cuda.current_stream()
 sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-run("one lane, 1024 pairs per step", [A], b1024, 1024, [cur])
-run("one lane, 512 pairs per step", [A], b512, 512, [cur])
-run("two lanes x 512 (caller's stream + one more)", [A, Bm], b512, 512, [cur, sB])
-run("two lanes x 512 (two streams of their own)", [A, Bm], b512, 512, [sA, sB])
-run("two lanes x 512, both on the caller's stream", [A, Bm], b512, 512, [cur, cur])
-run("one lane, 1024 pairs per step (again)", [A], b1024, 1024, [cur])
+ONLY = os.environ.get("LANE_ONLY")
+if ONLY is None:
+  run("one lane, 1024 pairs per step", [A], b1024, 1024, [cur])
+  run("one lane, 512 pairs per step", [A], b512, 512, [cur])
+  run("two lanes x 512 (caller's stream + one more)", [A, Bm], b512, 512, [cur, sB])
+  run("two lanes x 512 (two streams of their own)", [A, Bm], b512, 512, [sA, sB])
+  run("two lanes x 512, both on the caller's stream", [A, Bm], b512, 512, [cur, cur])
+  run("one lane, 1024 pairs per step (again)", [A], b1024, 1024, [cur])
+
+
+# ---- the staggered schedule: encoder chains of both halves on the caller's stream, the latency-bound middle (co-attention, MLP,
+# loss and their backward) of each half on a second stream, under the other half's encoder kernels ----
+from bmp.dp import _Unflatten
+
+
+def phase1(lane, pb):
+    m, o = lane
+    leaf = o.flat.detach().requires_grad_()
+    o._leaf = leaf
+    views = _Unflatten.apply(leaf, o.shapes)
+    plan = o._layout_plan()
+    plan.prepare(o.flat)
+    tape = leaf[:1]
+    for prefix, mod in o._plan_sections:
+        mod._fast = (plan.P[prefix], plan.G[prefix], plan.state, tape)
+    slots = o._param_slots()
+    for (reg, key, _orig), k in slots:
+        reg[key] = views[k]
+    m.graph_conv._readout_off_chain = True
+    enc = m._encode(pb, None, None, None)
+    m.graph_conv._readout_off_chain = False
+    return enc, slots
+
+
+def phase2(lane, enc, slots, t):
+    m, o = lane
+    g1, g2, at1, at2, mol0 = enc
+    g1, g2 = m.attn(at1, g1, at2, g2, mol0=mol0)
+    y = m.mlp(g1, g2)
+    for (reg, key, orig), _k in slots:
+        reg[key] = orig
+    for _p, mod in o._plan_sections:
+        mod._fast = None
+    return m.loss(y, t)
+
+
+def staggered(name, lanes, bs, B, s2):
+    cur = torch.cuda.current_stream()
+
+    def round_(i):
+        (pbA, tA), (pbB, tB) = bs[(2 * i) % len(bs)], bs[(2 * i + 1) % len(bs)]
+        eA = phase1(lanes[0], pbA); evA = cur.record_event()
+        eB = phase1(lanes[1], pbB); evB = cur.record_event()
+        with torch.cuda.stream(s2):
+            s2.wait_event(evA)
+            lA = phase2(lanes[0], *eA, tA)
+            lA.backward()          # (inside the context: the root gradient's fill must not queue behind the other half's encoder)
+        with torch.cuda.stream(s2):
+            s2.wait_event(evB)
+            lB = phase2(lanes[1], *eB, tB)
+            lB.backward()
+        cur.wait_stream(s2)
+        for m, o in lanes:
+            o.collect_grads(); o.step()
+        return lA, lB
+    for i in range(6):
+        round_(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        l = round_(i)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{name:46s} {steps * 2 * B / dt / 1e3:8.1f} k pairs/s   {dt / steps * 1e3:6.3f} ms per round   host {t_host / steps * 1e3:6.3f} ms"
+          f"   losses {float(l[0]):.4f} {float(l[1]):.4f}", flush=True)
+
+
+staggered("two halves staggered (middle on a 2nd stream)", [A, Bm], b512, 512, sB)
+if ONLY is None:
+    run("one lane, 1024 pairs per step (again)", [A], b1024, 1024, [cur])
