@@ -733,8 +733,10 @@ class PReadoutFn(Function):
         if side is not None:
             # enqueued LATER (flush_deferred: once the co-attention's forward launches are in their queue): launched here,
             # its 455 one-per-CU workgroups take the CUs before the chain's next launches get to them
+            # (no backward will read ij -- the output cannot be differentiated in this form --, so the tile kernel keeps none:
+            #  60 MB less to write per C2 step)
             tile = pb.row_mol is not None and not pb.oversized and bool(L.bmp_readout_tile_supported(d, d0, o))
-            ij = None if (infer and tile) else torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
+            ij = None if tile else torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
             g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
 
             def launch():

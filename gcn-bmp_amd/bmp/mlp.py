@@ -71,7 +71,9 @@ class MLPFn(Function):
         nws = L.bmp_mlp_bwd_ws_floats(B, nl, cd)
         ws = torch.empty(max(nws, 4), dtype=torch.float32, device=dev)
         from .functional import _side_handle
-        st_w = _side_handle(state, (ws,)) if G is not None else None       # the partials' fold beside the chain (planned path)
+        # the weight-gradient partials and their fold beside the chain (planned path): that launch reads dy, the inputs and the
+        # saved activations, which therefore stay alive until the streams have joined
+        st_w = _side_handle(state, (ws, dy, x1, x2, *acts)) if G is not None else None
         check(L.bmp_mlp_bwd(ptr(dy), ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(acts), ptr(dx1), ptr(dx2),
                             _parr(dW), _parr(db), ptr(ws), nws, stream(), st_w), "bmp_mlp_bwd")
         if G is not None:

@@ -43,6 +43,9 @@ struct CoArgs {
     // the oversized class (BIG kernels: a molecule of more than CO_MAXN rows): the arrays the other classes keep in LDS
     // live in a global workspace, one slice of big_stride floats per workgroup
     float* big_ws; long long big_stride;
+    // backward: row -> molecule maps of the two sides (-1: a row of no molecule) and their row counts; null = the caller has
+    // cleared the arrays
+    const int* rm1; const int* rm2; int N1, N2;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -419,6 +422,18 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     const int n1p = nb1 * 32, n2p = nb2 * 32;
     const CoLds L = BIG ? co_carve(a.big_ws + (size_t)blockIdx.x * a.big_stride, a.np, ldc, H, true, o, NT, true)
                         : co_carve(lds_raw, a.np, ldc, H, true, o, NT);
+    // ---- rows of no molecule must read as zero in the GEMMs that follow the pair kernels: the dead rows of a tile sit behind
+    // its last molecule, so the pair that owns that molecule clears them (a launch of its own for this was 23 us of the chain)
+    if (a.rm1 != nullptr) {
+        for (int row = r1 + n1; row < a.N1 && a.rm1[row] < 0; ++row) {
+            for (int c = tid; c < d; c += NT) a.dX1[(size_t)row * d + c] = 0.f;
+            for (int c = tid; c < ZC; c += NT) a.dZ1[(size_t)row * ZC + c] = 0.f;
+        }
+        for (int row = r2 + n2; row < a.N2 && a.rm2[row] < 0; ++row) {
+            for (int c = tid; c < d; c += NT) a.dQ2[(size_t)row * d + c] = 0.f;
+            for (int c = tid; c < ZC; c += NT) a.dZ2[(size_t)row * ZC + c] = 0.f;
+        }
+    }
     // ---- load the pair's saved state ----
     {   // column / row softmax statistics of C: saved by the forward behind the pair's C block
         const float* st = a.Cbuf + a.coff[b] + (size_t)n2 * n1;
@@ -892,42 +907,6 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     return 0;
 }
 
-// What the pair kernels of the backward do not write in the four arrays its GEMMs read whole: rows that belong to no
-// molecule (row_mol < 0), and in every other row the padding columns [zc_used, ZC) of dZ.
-__global__ __launch_bounds__(256) void k_zero_dead_rows(const int* __restrict__ rm1, const int* __restrict__ rm2, int N1, int N2,
-                                                        int d, int ZC, int zc_used, float* dX1, float* dZ1, float* dQ2,
-                                                        float* dZ2) {
-    // 256 rows per workgroup.  Nearly every row is live and only needs its (at most 7) padding columns of dZ cleared: one
-    // thread per row does that; the few dead rows of the workgroup are then cleared whole by all of its threads together.
-    // (One wave per row, the first form, was 14 600 workgroups and 22 us for a few hundred kilobytes of zeros.)
-    __shared__ int dead[256];
-    __shared__ int ndead;
-    const int tid = threadIdx.x;
-    if (tid == 0) ndead = 0;
-    __syncthreads();
-    const int row = blockIdx.x * 256 + tid;
-    if (row < N1 + N2) {
-        const bool s1 = row < N1;
-        const int r = s1 ? row : row - N1;
-        if ((s1 ? rm1[r] : rm2[r]) >= 0) {
-            float* dz = (s1 ? dZ1 : dZ2) + (size_t)r * ZC;
-            for (int c = zc_used; c < ZC; ++c) dz[c] = 0.f;
-        } else {
-            dead[atomicAdd(&ndead, 1)] = row;          // (LDS counter: the order of the list does not matter, zeros are zeros)
-        }
-    }
-    __syncthreads();
-    for (int k = 0; k < ndead; ++k) {
-        const int rw = dead[k];
-        const bool s1 = rw < N1;
-        const int r = s1 ? rw : rw - N1;
-        float* dx = (s1 ? dX1 : dQ2) + (size_t)r * d;
-        float* dz = (s1 ? dZ1 : dZ2) + (size_t)r * ZC;
-        for (int c = tid; c < d; c += 256) dx[c] = 0.f;
-        for (int c = tid; c < ZC; c += 256) dz[c] = 0.f;
-    }
-}
-
 extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B, int nbig, int np_big) {
     const int ZC = bmp_coattn_zcols(o, H);
     const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
@@ -976,15 +955,9 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     float* slab = dpart + (size_t)B * (2 * H + 1);
     hipError_t e;
     // rows outside every pair (dead rows) must read as zero in the GEMMs below: the pair kernels write every row of every
-    // molecule, so with the row -> molecule maps of the packed batches (-1: no molecule) only those rows are cleared
-    // (a few hundred rows instead of 125 MB of fills); without the maps everything is
-    if (row_mol1 && row_mol2) {
-        // (the padding columns [o + H + 1, ZC) of the LIVE rows are cleared by the pair kernels next to the dv column they write;
-        //  one thread per row doing it here was 58 k partial cache lines and 23 us)
-        hipLaunchKernelGGL(k_zero_dead_rows, dim3((N1 + N2 + 255) / 256), dim3(256), 0, st, row_mol1, row_mol2, N1, N2, d, ZC, ZC, dX1,
-                           dZ1, dQ2, dZ2);
-        BMP_LAUNCH_CHECK();
-    } else {
+    // molecule (its dZ padding columns included) and, with the row -> molecule maps of the packed batches (-1: no molecule),
+    // the dead rows behind a tile's last molecule; without the maps everything is cleared first (125 MB of fills at C2)
+    if (!(row_mol1 && row_mol2)) {
         if ((e = hipMemsetAsync(dQ2, 0, ((size_t)N2 * d + (size_t)(N1 + N2) * ZC) * sizeof(float), st)) != hipSuccess) return (int)e;
         if ((e = hipMemsetAsync(dX1, 0, (size_t)N1 * d * sizeof(float), st)) != hipSuccess) return (int)e;
     }
@@ -996,6 +969,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     a.Cbuf = const_cast<float*>(Cbuf); a.H1 = const_cast<float*>(H1); a.H2 = const_cast<float*>(H2);
     a.al1 = const_cast<float*>(al1); a.al2 = const_cast<float*>(al2);
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
+    if (row_mol1 && row_mol2) { a.rm1 = row_mol1; a.rm2 = row_mol2; a.N1 = N1; a.N2 = N2; }
     if (!st_w) st_w = st;
     {
         const int cnt[4] = {n32, n64, n96, n128};

@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
 }
 
 // slab layout per workgroup: for every layer l: dW[l] [no x ni] then db[l] [no]
+// DX: the gradient of the MLP's input rows (what the backward chain waits for); DW: the workgroup's weight / bias gradient
+// partials (35 KB per workgroup at 256 -> 32 -> 16 -> 1, folded by k_mlp_reduce).  The chain launches <true, false>, the
+// stream beside it <false, true>: both walk the few hundred multiply-adds per row of the layers' backprop themselves.
+template <bool DX, bool DW>
 __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
     __shared__ float xin[MLP_BR][MLP_MAXIN];              // layer-0 input rows
     __shared__ float hid[MLP_MAXL][MLP_BR][MLP_MAXW];     // relu outputs of the hidden layers
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * MLP_BR;
     const int in0 = a.dims[0];
+    if (DW)
     for (int idx = tid; idx < MLP_BR * in0; idx += 256) {
         const int r = idx / in0, k = idx % in0, row = row0 + r;
         float v = 0.f;
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
         const float* __restrict__ W = a.W[l];
         // weight / bias gradient partials of this workgroup's rows
         float* dW = slab + off_l[l];
+        if (DW) {
         for (int k = tid; k < ni; k += 256) {             // thread owns input column k: its MLP_BR inputs stay in registers
             float xk[MLP_BR];
 #pragma unroll
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
             for (int r = 0; r < MLP_BR; ++r) acc += dcur[cur][r][j];
             dW[no * ni + j] = acc;
         }
+        }
         // gradient w.r.t. the layer input
         if (l > 0) {
             for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
@@ -132,14 +139,25 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
                 for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
                 dcur[cur ^ 1][r][k] = hid[l - 1][r][k] > 0.f ? acc : 0.f;
             }
-        } else {
-            for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
-                const int r = idx / ni, k = idx % ni, row = row0 + r;
-                if (row >= a.B) continue;
-                float acc = 0.f;
-                for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
-                if (k < a.d1) a.dx1[(size_t)row * a.d1 + k] = acc;
-                else a.dx2[(size_t)row * a.d2 + (k - a.d1)] = acc;
+        } else if (DX) {
+            // a thread owns input column k for all rows of the workgroup: W[j][k] is read once per j, not once per row and j
+            // (256 loads per thread in the row-major walk: most of this launch's 37 us)
+            for (int k = tid; k < ni; k += 256) {
+                float acc[MLP_BR];
+#pragma unroll
+                for (int r = 0; r < MLP_BR; ++r) acc[r] = 0.f;
+                for (int j = 0; j < no; ++j) {
+                    const float wv = W[(size_t)j * ni + k];
+#pragma unroll
+                    for (int r = 0; r < MLP_BR; ++r) acc[r] += dcur[cur][r][j] * wv;
+                }
+#pragma unroll
+                for (int r = 0; r < MLP_BR; ++r) {
+                    const int row = row0 + r;
+                    if (row >= a.B) continue;
+                    if (k < a.d1) a.dx1[(size_t)row * a.d1 + k] = acc[r];
+                    else a.dx2[(size_t)row * a.d2 + (k - a.d1)] = acc[r];
+                }
             }
         }
         __syncthreads();
@@ -229,11 +247,19 @@ extern "C" int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float
     }
     r.off[nl] = off; r.nl = nl; r.slab = ws; r.nslab = nwg; r.stride = off;
     a.dy = dy; a.dx1 = dx1; a.dx2 = dx2; a.slab = ws; a.slab_stride = off;
-    hipLaunchKernelGGL(k_mlp_bwd, dim3(nwg), dim3(256), 0, st, a);
-    BMP_LAUNCH_CHECK();
-    // the fold of the per-workgroup weight-gradient partials is off the backward chain: stream_w (bmp.h, "stream_w")
-    if (!st_w) st_w = st;
-    if ((rc = bmp_fork_to(st, st_w))) return rc;
+    // the weight-gradient partials and their fold are off the backward chain: stream_w (bmp.h, "stream_w"); the chain's launch
+    // only hands the input gradients on
+    if (!st_w || st_w == st) {
+        hipLaunchKernelGGL((k_mlp_bwd<true, true>), dim3(nwg), dim3(256), 0, st, a);
+        BMP_LAUNCH_CHECK();
+        st_w = st;
+    } else {
+        if ((rc = bmp_fork_to(st, st_w))) return rc;          // dy is ready on `st`
+        hipLaunchKernelGGL((k_mlp_bwd<true, false>), dim3(nwg), dim3(256), 0, st, a);
+        BMP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_mlp_bwd<false, true>), dim3(nwg), dim3(256), 0, st_w, a);
+        BMP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 63) / 64), dim3(256), 0, st_w, r);
     BMP_LAUNCH_CHECK();
     return 0;
