@@ -315,8 +315,9 @@ def main():
 
         def train_step(self, pb, t, collective=True):
             opt = self.opt
-            y = opt.functional_forward(pb)          # parameters = views of the flat buffer, ONE gradient tensor
-            loss = self.model.loss(y, t)
+            # parameters = views of the flat buffer, ONE gradient tensor; the model's forward_loss = the reference's Classifier
+            # (train_ddi_modify.py:284-286): encoder, co-attention, link predictor and the loss against the labels
+            loss = opt.functional_loss(pb, t=t)
             loss.backward()
             opt.collect_grads()
             if collective:                          # the roofline leg runs on rank 0 alone: no collective there

@@ -82,6 +82,9 @@ SIGNATURES = {
     "bmp_mlp_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "bmp_mlp_bwd_ws_floats": (_Z, [_I, _I, _P]),
     "bmp_mlp_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
+    "bmp_mlp_sce_ws_floats": (_Z, [_I]),
+    "bmp_mlp_sce_fwdbwd": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "bmp_mlp_bwd_w": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "bmp_sce_fwd": (_I, [_P, _P, _I, _P, _P, _P]),
     "bmp_sce_bwd": (_I, [_P, _P, _I, _P, _P, _P, _P]),
     "bmp_pairfeat_cols": (_I, [_I, _I, _I]),
@@ -93,7 +96,7 @@ SIGNATURES = {
     "bmp_coattn_nie_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 17 + [_P, _Z, _P]),
     "bmp_coattn_big_ws_floats": (_Z, [_I] * 5),
     "bmp_coattn_nie_bwd_ws_floats": (_Z, [_I] * 8),
-    "bmp_coattn_nie_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 21 + [_Z, _P, _P, _P, _P]),
+    "bmp_coattn_nie_bwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 7 + [_I, _P, _I, _I, _I, _I, _I, _I] + [_P] * 21 + [_Z, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -161,7 +161,7 @@ class NieCoattnFn(Function):
                                    ptr(wa2),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(dWbT), ptr(dZW1T), ptr(dZW2T), ptr(dzb), ptr(dwa), ptr(ws), nws,
-                                   stream(), None, None, None), "bmp_coattn_nie_bwd")
+                                   stream(), None, None, None, None), "bmp_coattn_nie_bwd")
         return (dX1, dX2, dWbT, dZW1T, dZW2T, dzb, dwa[:H], dwa[H:2 * H], dwa[2 * H:], None, None, None, None, None,
                 None, None, None)
 
@@ -213,6 +213,16 @@ class PNieFn(Function):
         d, o, H, act, ZC, mode = ctx.dims
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         dout1, dout2 = dout1.contiguous(), dout2.contiguous()
+        # bmp.mlp.MLPLossFn hands over the gradients of the mean loss for d loss = 1 and leaves the factor that arrived at the
+        # loss (a device scalar) here: the pair kernels multiply on load
+        gs = None
+        hs = ctx.state.pop("head_gscale", None) if ctx.state is not None else None
+        if hs is not None:
+            g, u1, u2 = hs
+            if dout1.data_ptr() == u1.data_ptr() and dout2.data_ptr() == u2.data_ptr():
+                gs = g
+            else:       # something else was added to the head's gradients on the way here: put the factor on the head's share
+                dout1, dout2 = dout1 + (g - 1.0) * u1, dout2 + (g - 1.0) * u2
         if ctx.joint:
             dX = torch.empty(X1.shape[0] + X2.shape[0], d, dtype=torch.float32, device=X1.device)
             dX1, dX2 = dX[:X1.shape[0]], dX[X1.shape[0]:]
@@ -226,8 +236,10 @@ class PNieFn(Function):
                                    ptr(W["ZW2"]), ptr(W["wa1"]), ptr(W["wa2"]),
                                    ptr(Q2), ptr(Z1), ptr(Z2), ptr(Cbuf), ptr(H1), ptr(H2), ptr(al1), ptr(al2), ptr(dX1),
                                    ptr(dX2), ptr(G["dWbT"]), ptr(G["dZW1T"]), ptr(G["dZW2T"]), ptr(G["dzb"]), ptr(G["dwa"]),
-                                   ptr(ws), nws, stream(), _side_handle(ctx.state, (X1, X2, ws)), ptr(ctx.rm[0]), ptr(ctx.rm[1])),
-              "bmp_coattn_nie_bwd")
+                                   ptr(ws), nws, stream(), _side_handle(ctx.state, (X1, X2, ws)), ptr(ctx.rm[0]), ptr(ctx.rm[1]),
+                                   ptr(gs)), "bmp_coattn_nie_bwd")
+        from .functional import flush_deferred_bwd
+        flush_deferred_bwd(ctx.state)
         if ctx.joint:
             return (dX,) + (None,) * 15
         return (dX1, dX2) + (None,) * 14

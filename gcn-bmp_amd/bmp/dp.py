@@ -102,6 +102,9 @@ class FlatAdam:
     def functional_forward(self, *args, **kwargs):
         """Run the module on parameter views produced by ONE autograd node over the flat buffer.
         After ``loss.backward()`` call ``collect_grads()``; the flat gradient is then in ``self.grad``."""
+        return self._functional(self.module, args, kwargs)
+
+    def _functional(self, call, args, kwargs):
         leaf = self.flat.detach().requires_grad_()
         self._leaf = leaf
         views = _Unflatten.apply(leaf, self.shapes)
@@ -122,12 +125,18 @@ class FlatAdam:
         try:
             for (reg, key, _orig), k in slots:
                 reg[key] = views[k]
-            return self.module(*args, **kwargs)
+            return call(*args, **kwargs)
         finally:
             for (reg, key, orig), _k in slots:
                 reg[key] = orig
             for mod in hooked:
                 mod._fast = None
+
+    def functional_loss(self, *args, t):
+        """``functional_forward`` through the module's ``forward_loss`` (GraphConvPredictorForPair: the reference's Classifier,
+        train_ddi_modify.py:284-286): the loss of the batch against the labels ``t``, with link predictor + loss as one launch
+        each way where the module offers it.  Then ``loss.backward()``, ``collect_grads()``, ``step()`` as usual."""
+        return self._functional(lambda *a: self.module.forward_loss(*a, t=t), args, {})
 
     def functional_predict(self, *args, **kwargs):
         """The evaluation callers' ``predict`` (eval_coattention.py:103-124; training/extensions/batch_evaluator.py:49-100 runs it

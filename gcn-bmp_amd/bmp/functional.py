@@ -294,6 +294,17 @@ class GGNNStepFn(Function):
         return dh, dWT, dbE, dAT, dUcT, cs[4 * d:], None, None, None
 
 
+def flush_deferred_bwd(state) -> None:
+    """Backward launches held back so that they queue on the weight-gradient stream BEHIND the launches of the node that
+    follows (bmp.mlp.MLPLossFn: the link predictor's weight-gradient partials are nobody's input, the largest size class of the
+    pair kernels -- same stream -- is the chain's)."""
+    if state is not None and state.get("deferred_bwd"):
+        fns = state["deferred_bwd"]
+        state["deferred_bwd"] = []
+        for fn in fns:
+            fn()
+
+
 def flush_deferred(state) -> None:
     """Launch what PReadoutFn's off-chain form held back."""
     if state is not None and state.get("deferred"):
@@ -519,6 +530,7 @@ _FORK_ONCE = os.environ.get("BMP_FWD_FORK_ONCE", "1") != "0"          # A/B swit
 _ENC_SPLIT = os.environ.get("BMP_ENC_SPLIT", "0") == "1"             # A/B: two chains also over an encoder-layout tile table
 _RO_DEFER = os.environ.get("BMP_READOUT_DEFER", "1") != "0"
 _RO_OFF_CHAIN = os.environ.get("BMP_READOUT_OFF_CHAIN", "1") != "0"        # A/B switch of PReadoutFn's off_chain form
+_RO_PART = os.environ.get("BMP_READOUT_STREAM", "part") == "part"          # A/B: the off-chain readout on the part / the side stream
 
 
 def _on_side(state, keep, launch) -> None:
@@ -739,7 +751,18 @@ class PReadoutFn(Function):
             ij = None if tile else torch.empty(N, 2 * o, dtype=torch.float32, device=h.device)
             g = torch.empty(pb.n_mols, o, dtype=torch.float32, device=h.device)
 
+            sp = state.get("split") if _RO_PART else None
+
             def launch():
+                if sp is not None:
+                    # on the forward's second-chain stream, idle by now: the weight-gradient stream's queue stays free for the
+                    # launches of the backward that follow at once (the link predictor's partials, the largest size class of the
+                    # pair kernels), which otherwise wait behind this one
+                    sp.stream.wait_stream(torch.cuda.current_stream())
+                    _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o, sp.handle, out=(ij, g))
+                    state.setdefault("split_keep", []).append((h, h0, ij, g))
+                    state["split_open"] = True
+                    return
                 side.stream.wait_stream(torch.cuda.current_stream())
                 _readout_fwd(h, h0, pb, WT, W.get("WTp"), W.get("b"), act_j, o, side.handle, out=(ij, g))
                 side.keep.append((h, h0, ij, g))

@@ -81,6 +81,107 @@ class MLPFn(Function):
         return (None, dx1, dx2, None, None) + tuple(dW) + tuple(db)
 
 
+_TICKETS = {}
+
+
+def _ticket(device) -> torch.Tensor:
+    """The zero word of bmp_mlp_sce_fwdbwd (zero before every launch, put back to zero by the launch), one per device."""
+    k = (device.type, device.index)
+    if k not in _TICKETS:
+        _TICKETS[k] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _TICKETS[k]
+
+
+class MLPLossFn(Function):
+    """relu-MLP on [x1 | x2] AND the mean sigmoid cross entropy of its logits against ``t`` -- what the reference's
+    Classifier(predictor, lossfun=F.sigmoid_cross_entropy) computes around the link predictor (train_ddi_modify.py:284-286) -- as
+    ONE forward launch that also takes the loss gradient back to the input rows (bmp_mlp_sce_fwdbwd); the backward scales those
+    rows by the gradient that arrives at the loss and folds the weight gradients beside the chain (bmp_mlp_bwd_w).
+    Returns (loss, logits); the logits are not differentiable here (the loss is the only way back)."""
+
+    @staticmethod
+    def forward(ctx, tape, x1, x2, t, G, state, consumer_scales, *wb):
+        from . import _lib
+        from ._lib import check, ptr, stream
+        L = _lib.lib()
+        nl = len(wb) // 2
+        Ws = [w.contiguous() for w in wb[:nl]]
+        bs = [None if b is None else b.contiguous() for b in wb[nl:]]
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        B, d1 = x1.shape
+        d2 = 0 if x2 is None else x2.shape[1]
+        dims = [d1 + d2] + [w.shape[0] for w in Ws]
+        dev = x1.device
+        t = t.to(torch.int32).contiguous()
+        if t.numel() != B * dims[-1]:
+            raise ValueError(f"labels: {tuple(t.shape)} for {B} rows of {dims[-1]} logits")
+        cd = (ctypes.c_int * len(dims))(*dims)
+        f = lambda *s_: torch.empty(*s_, dtype=torch.float32, device=dev)
+        acts = [f(B, n) for n in dims[1:]]
+        dy, dx = f(B, dims[-1]), f(B * (d1 + d2))
+        dx1, dx2 = dx[:B * d1].view(B, d1), (dx[B * d1:].view(B, d2) if d2 else None)
+        loss, sums, part = f(()), f(2), f(max(int(L.bmp_mlp_sce_ws_floats(B)), 1))
+        check(L.bmp_mlp_sce_fwdbwd(ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(bs), _parr(acts), ptr(t), ptr(dy),
+                                   ptr(dx1), ptr(dx2), ptr(loss), ptr(sums), ptr(part), ptr(_ticket(dev)), stream()),
+              "bmp_mlp_sce_fwdbwd")
+        ctx.kept = (x1, x2, Ws, acts, dy, dx, dx1, dx2)
+        ctx.meta = (nl, dims, [b is not None for b in bs], G, state)
+        ctx.mark_non_differentiable(acts[-1])
+        ctx.set_materialize_grads(False)
+        ctx.consumer_scales = consumer_scales
+        return loss, acts[-1]
+
+    @staticmethod
+    def backward(ctx, gloss, _gy):
+        from . import _lib
+        from ._lib import check, ptr, stream
+        L = _lib.lib()
+        nl, dims, has_b, G, state = ctx.meta
+        x1, x2, Ws, acts, dy, dx, dx1, dx2 = ctx.kept
+        B, d1 = x1.shape
+        d2 = dims[0] - d1
+        dev = x1.device
+        cd = (ctypes.c_int * len(dims))(*dims)
+        if G is not None:
+            dW = [G[f"dW{l}"] for l in range(nl)]
+            db = [G[f"db{l}"] if has_b[l] else None for l in range(nl)]
+        else:
+            dW = [torch.empty_like(w) for w in Ws]
+            db = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) if has_b[l] else None for l, w in enumerate(Ws)]
+        nws = L.bmp_mlp_bwd_ws_floats(B, nl, cd)
+        ws = torch.empty(max(nws, 4), dtype=torch.float32, device=dev)
+        if gloss is None:                                    # the loss does not reach the root of this backward
+            gloss = torch.zeros(1, dtype=torch.float32, device=dev)
+        gloss = gloss.contiguous().to(torch.float32).reshape(1)
+        if ctx.consumer_scales and state is not None:
+            state["head_gscale"] = (gloss, dx1, dx2)         # PNieFn.backward (the node both input blocks come from) multiplies
+            gx = dx
+        else:
+            gx = dx * gloss                                  # one launch over both input blocks
+        def weight_grads():
+            st_w = None
+            if G is not None:
+                from .functional import _side_handle
+                st_w = _side_handle(state, (ws, dy, x1, x2, gloss, *acts))
+            if st_w is not None:
+                state["side"].stream.wait_stream(torch.cuda.current_stream())
+            check(L.bmp_mlp_bwd_w(ptr(dy), ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(acts), _parr(dW), _parr(db),
+                                  ptr(gloss), ptr(ws), nws, st_w if st_w is not None else stream()), "bmp_mlp_bwd_w")
+        if ctx.consumer_scales and state is not None:
+            # behind the co-attention's backward launches in the weight-gradient stream's queue (flushed by PNieFn.backward):
+            # in front of them, these partials -- nobody's input -- delayed the pair kernels' largest size class, which the
+            # backward chain waits for
+            state.setdefault("deferred_bwd", []).append(weight_grads)
+        else:
+            weight_grads()
+        gx1 = gx[:B * d1].view(B, d1)
+        gx2 = gx[B * d1:].view(B, d2) if d2 else None
+        if G is not None:
+            return (None, gx1, gx2, None, None, None, None) + (None,) * (2 * nl)
+        return (None, gx1, gx2, None, None, None, None) + tuple(dW) + tuple(db)
+
+
 class SCEFn(Function):
     """chainer.functions.sigmoid_cross_entropy (train_ddi_modify.py:285)."""
 
@@ -194,3 +295,25 @@ class MLP(nn.Module):
         for l in self.layers:                                   # models/mlp.py:42-43
             h = self.activation(torch.nn.functional.linear(h, l.W, l.b))
         return torch.nn.functional.linear(h, self.l_out.W, self.l_out.b)
+
+    def forward_loss(self, x, x2, t):
+        """(mean sigmoid cross entropy of the logits against ``t``, logits): the reference's Classifier around this link
+        predictor (train_ddi_modify.py:284-286).  On the device, with gradients on, one launch each way (MLPLossFn); otherwise
+        ``forward`` followed by ``sigmoid_cross_entropy``."""
+        if x.is_cuda and torch.is_grad_enabled() and self.in_dim is not None and self._kernel_ok() and \
+                x.shape[-1] + (0 if x2 is None else x2.shape[-1]) == self.in_dim:
+            ls = self._linears()
+            fast = getattr(self, "_fast", None)
+            if fast is not None:
+                P, G, state, tape = fast
+                wb = [P[f"W{k}"] for k in range(len(ls))] + [P[f"b{k}"] for k in range(len(ls))]
+                # both input blocks straight out of ONE planned co-attention node: that node's backward takes the factor that
+                # arrives at the loss (a device scalar) into its pair kernels, instead of a launch that scales the rows here
+                fn1, fn2 = getattr(x, "grad_fn", None), getattr(x2, "grad_fn", None)
+                direct = fn1 is not None and fn1 is fn2 and type(fn1).__name__ == "PNieFnBackward" and state is not None
+                loss, y = MLPLossFn.apply(tape, x, x2, t, G, state, direct, *wb)
+            else:
+                loss, y = MLPLossFn.apply(None, x, x2, t, None, None, False, *[l.W for l in ls], *[l.b for l in ls])
+            return loss, y
+        y = self.forward(x, x2)
+        return sigmoid_cross_entropy(y, t), y

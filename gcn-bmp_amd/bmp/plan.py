@@ -277,6 +277,9 @@ class LayoutPlan:
             if self.state.get("deferred"):
                 from .functional import flush_deferred
                 flush_deferred(self.state)
+            if self.state.get("deferred_bwd"):
+                from .functional import flush_deferred_bwd
+                flush_deferred_bwd(self.state)
             if self.state.get("side_used"):          # the side stream's weight gradients land in gk
                 self.state["side"].join()
                 self.state["side_used"] = False

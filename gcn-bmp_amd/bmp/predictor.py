@@ -63,6 +63,17 @@ class GraphConvPredictorForPair(nn.Module):
         return g1, g2, at1, at2, (0, 0)
 
     def forward(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
+        return self._forward(atoms_1, adjs_1, atoms_2, adjs_2, None)
+
+    def forward_loss(self, *inputs, t):
+        """``Classifier(predictor, lossfun=F.sigmoid_cross_entropy)(*inputs, t)`` (train_ddi_modify.py:284-286;
+        train_binary.py:520-524): the mean sigmoid cross entropy of the pair logits against the labels ``t`` (-1: not counted).
+        With an MLP link predictor on the device the link predictor, the loss and their backward are one launch each way
+        (bmp.mlp.MLPLossFn); the logits of the call are left in ``self.y``."""
+        inputs = tuple(inputs) + (None,) * (4 - len(inputs))
+        return self._forward(*inputs, t)
+
+    def _forward(self, atoms_1, adjs_1, atoms_2, adjs_2, t):
         # A co-attention of the fine family replaces the encoder's molecule vectors without reading them (:96 with
         # nie_coattention.py:335-370): the readout is computed all the same, but a planned encoder may take it off the chain
         self.graph_conv._readout_off_chain = bool(getattr(self.attn, "ignores_graph_vectors", False))
@@ -77,7 +88,13 @@ class GraphConvPredictorForPair(nn.Module):
             from .functional import flush_deferred
             flush_deferred(fast[2])
         self.g1, self.g2 = g1, g2
-        return self.mlp(g1, g2)          # MLP on [g1 | g2] :98-101 (no concatenation copy); NTN / HolE / ... :102-116
+        if t is None:
+            return self.mlp(g1, g2)      # MLP on [g1 | g2] :98-101 (no concatenation copy); NTN / HolE / ... :102-116
+        if callable(getattr(self.mlp, "forward_loss", None)):
+            loss, self.y = self.mlp.forward_loss(g1, g2, t)
+            return loss
+        self.y = self.mlp(g1, g2)
+        return self.loss(self.y, t)
 
     def predict(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):
         """train_binary.py:120-127 (sigmoid under no-backprop)."""

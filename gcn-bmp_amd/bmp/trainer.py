@@ -219,8 +219,10 @@ def fit(model, opt, train_batches: Sequence, valid_batches: Sequence = (), epoch
     for epoch in range(1, epochs + 1):
         tot, n = None, 0
         for pb, t in train_batches:
-            y = opt.functional_forward(pb)
-            loss = model.loss(y, t)
+            if callable(getattr(model, "forward_loss", None)):      # the reference's Classifier: link predictor + loss together
+                loss = opt.functional_loss(*(pb if isinstance(pb, (tuple, list)) else (pb,)), t=t)
+            else:
+                loss = model.loss(opt.functional_forward(pb), t)
             loss.backward()
             opt.collect_grads()
             opt.all_reduce_grads()

@@ -46,6 +46,7 @@ struct CoArgs {
     // backward: row -> molecule maps of the two sides (-1: a row of no molecule) and their row counts; null = the caller has
     // cleared the arrays
     const int* rm1; const int* rm2; int N1, N2;
+    const float* gscale;                       // backward: device scalar dout1 / dout2 are multiplied with on load (null: 1)
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -449,7 +450,10 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
     for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n1 * H; idx += NT) L.H1s[idx] = a.H1[(size_t)r1 * H + idx];
     for (int idx = tid; idx < n2 * H; idx += NT) L.H2s[idx] = a.H2[(size_t)r2 * H + idx];
-    for (int c = tid; c < o; c += NT) { L.do1[c] = a.dout1[(size_t)b * o + c]; L.do2[c] = a.dout2[(size_t)b * o + c]; }
+    {
+        const float gs = a.gscale ? a.gscale[0] : 1.f;
+        for (int c = tid; c < o; c += NT) { L.do1[c] = a.dout1[(size_t)b * o + c] * gs; L.do2[c] = a.dout2[(size_t)b * o + c] * gs; }
+    }
     if constexpr (BIG) {
         for (int j = tid; j < n1; j += NT) { L.w1s[j] = a.w1[r1 + j]; L.s1[j] = a.al1[r1 + j]; }
         for (int i = tid; i < n2; i += NT) { L.w2s[i] = a.w2[r2 + i]; L.s2[i] = a.al2[r2 + i]; }
@@ -941,7 +945,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
                                   const float* H1, const float* H2, const float* al1, const float* al2, float* dX1,
                                   float* dX2, float* dWbT, float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws,
                                   size_t ws_floats, hipStream_t st, hipStream_t st_w, const int* row_mol1,
-                                  const int* row_mol2) {
+                                  const int* row_mol2, const float* gscale) {
     BMP_REQUIRE(d > 0 && (d & 7) == 0 && o > 0 && (o & 3) == 0 && H > 0 && H < CO_MAXH && B > 0);
     BMP_REQUIRE(order != nullptr && n32 >= 0 && n64 >= 0 && n96 >= 0 && n128 >= 0 && nbig >= 0 && n32 + n64 + n96 + n128 + nbig == B);
     BMP_REQUIRE(nbig == 0 || np_big > CO_MAXN);
@@ -970,6 +974,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     a.al1 = const_cast<float*>(al1); a.al2 = const_cast<float*>(al2);
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
     if (row_mol1 && row_mol2) { a.rm1 = row_mol1; a.rm2 = row_mol2; a.N1 = N1; a.N2 = N2; }
+    a.gscale = gscale;
     if (!st_w) st_w = st;
     {
         const int cnt[4] = {n32, n64, n96, n128};

@@ -787,18 +787,47 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
 // own row count, split size and slab).  For problems that are a launch of 1-2 tiles x ~128 splits each: back to back
 // every one of them lasts one workgroup's latency, side by side they share it.  ONE staging area: an LDS array per
 // instantiated body would halve the workgroups per CU.
-struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; };
+struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; int grouped, smax; };
 // STEP = 1: the launch of bmp_launch_wgrad_fused (same code; a separate symbol so that profiles tell the fused step
 // weight gradients from the co-attention's small three-problem launch)
 template <int STEP>
 __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
     __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
     __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
-    const int by = blockIdx.y;
+    int by, bz;
+    if (m.grouped) {
+        // XCD-grouped 1-D launch (wgrad_grouped_grid): workgroup L runs on XCD L % 8, and the launch fits the chip's slots, so
+        // the workgroups of an XCD are resident together.  All column tiles of a row split then sit on ONE XCD and walk the same
+        // rows of X and dY at about the same time: one fetch into that XCD's L2 serves them all (in the (tile, split) grid order
+        // the tiles of a split landed on eight different XCDs and every one of them fetched its operands from HBM itself: 658 MB
+        // per launch for 291 MB of operands).  G = smax / 8 splits live whole on every XCD; the tiles of the remaining
+        // smax % 8 splits fill the XCDs' last slots one by one.
+        const int T = m.ty0[3], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
+        if (slot < G * T) { bz = xcd * G + slot / T; by = slot % T; }
+        else {
+            const int r = (slot - G * T) * 8 + xcd;
+            if (r >= (m.smax - 8 * G) * T) return;
+            bz = 8 * G + r / T; by = r % T;
+        }
+    } else { by = blockIdx.y; bz = blockIdx.z; }
     const int p = by >= m.ty0[2] ? 2 : (by >= m.ty0[1] ? 1 : 0);
-    if ((int)blockIdx.z >= m.S[p]) return;
-    if (m.p[p].X2) wgrad_lds_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], blockIdx.z, XS, YS);
-    else wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], blockIdx.z, XS, YS);
+    if (bz >= m.S[p]) return;
+    if (m.p[p].X2) wgrad_lds_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, XS, YS);
+    else wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, XS, YS);
+}
+
+// Grid of a three-problem launch: XCD-grouped (see the kernel) when the work fits the chip's 512 slots in one round and there
+// is more than one column tile to share operands; else the plain (tile, split) grid.  BMP_WGRAD_XCD=0: always the plain grid.
+static dim3 wgrad_grouped_grid(WGKMulti& m, int smax) {
+    static const int on = [] { const char* e = getenv("BMP_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    const int T = m.ty0[3];
+    m.smax = smax; m.grouped = 0;
+    if (on && T > 1 && smax >= 8) {
+        const int G = smax >> 3;
+        const int slots = G * T + ((smax - 8 * G) * T + 7) / 8;
+        if (slots <= 64) { m.grouped = 1; return dim3(8 * slots, 1, 1); }
+    }
+    return dim3(1, T, smax);
 }
 
 // One reduction launch for the problems of a fused launch.  Walks the PHYSICAL output elements of every problem
@@ -989,7 +1018,8 @@ int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
     }
     {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, BMP_KID_WGRAD_MULTI);
-        hipLaunchKernelGGL((k_wgrad_lds_multi<0>), dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
+        const dim3 grid = wgrad_grouped_grid(m, smax);
+        hipLaunchKernelGGL((k_wgrad_lds_multi<0>), grid, dim3(256), 0, st, m);
     }
     BMP_LAUNCH_CHECK();
     for (int p = 0; p < n; ++p) {
@@ -1074,7 +1104,8 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
     for (int p = n; p <= 3; ++p) r.b0[p] = rb;
     if (m.ty0[3] > 0) {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, kid);
-        hipLaunchKernelGGL((k_wgrad_lds_multi<1>), dim3(1, m.ty0[3], smax), dim3(256), 0, st, m);
+        const dim3 grid = wgrad_grouped_grid(m, smax);
+        hipLaunchKernelGGL((k_wgrad_lds_multi<1>), grid, dim3(256), 0, st, m);
     }
     BMP_LAUNCH_CHECK();
     if (rb > 0) hipLaunchKernelGGL(k_reduce_multi, dim3(rb), dim3(256), 0, st, r);

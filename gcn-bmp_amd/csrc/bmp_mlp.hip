@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
 
 // out[i] = sum over workgroup slabs, fixed order; the outputs are scattered to per-layer arrays by the host
 // through pointer/offset pairs
-struct MlpRedArgs { const float* slab; int nslab, stride; float* dW[MLP_MAXL]; float* db[MLP_MAXL]; int off[MLP_MAXL + 1]; int nw[MLP_MAXL]; int nl; };
+struct MlpRedArgs { const float* slab; int nslab, stride; float* dW[MLP_MAXL]; float* db[MLP_MAXL]; int off[MLP_MAXL + 1]; int nw[MLP_MAXL]; int nl;
+                    const float* gscale; };        // device scalar every sum is multiplied with (null: 1)
 __global__ __launch_bounds__(256) void k_mlp_reduce(MlpRedArgs a) {
     __shared__ float red[4][64];
     const int total = a.off[a.nl];
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(MlpRedArgs a) {
     __syncthreads();
     if (g == 0 && i < total) {
         v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        if (a.gscale) v *= a.gscale[0];
         int l = 0;
         while (l + 1 < a.nl && i >= a.off[l + 1]) ++l;
         const int loc = i - a.off[l];
@@ -261,6 +263,201 @@ extern "C" int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float
         BMP_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 63) / 64), dim3(256), 0, st_w, r);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the whole head of a training step in one launch: MLP forward, sigmoid cross entropy, its gradient, MLP backward down
+// to the input rows (Classifier(predictor, lossfun=F.sigmoid_cross_entropy), train_ddi_modify.py:284-286, on
+// models/mlp.py:40-45).  As five launches (bmp_mlp_fwd, bmp_sce_fwd, the framework's fill of the root gradient, bmp_sce_bwd,
+// bmp_mlp_bwd) these few hundred multiply-adds per row were ~100 us of the step's dependent chain.  Same arithmetic and
+// summation orders per row as those launches.  dx is the gradient of the MEAN loss for d loss = 1 (the caller scales it, and
+// bmp_mlp_bwd_w the weight gradients, with the gradient that arrives at the loss).
+struct HeadArgs {
+    const int* t;          // labels [B x C] (C = dims[nl]), -1 = not counted
+    float* dy;             // [B x C] gradient of the mean loss w.r.t. the logits
+    float* part;           // [n workgroups] loss numerators of the workgroups' rows
+    unsigned* ticket;      // zero before the launch, zero again after it
+    float* loss; float* sums;       // mean loss; numerator | count
+};
+
+__global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
+    __shared__ float xin[MLP_BR][MLP_MAXIN];              // layer-0 input rows
+    __shared__ float hid[MLP_MAXL][MLP_BR][MLP_MAXW];     // layer outputs (relu; the last: logits)
+    __shared__ float dcur[2][MLP_BR][MLP_MAXW];
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    __shared__ int last_flag;
+    extern __shared__ float wt[];                         // first-layer weights, transposed: wt[k * (no + 1) + j]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row0 = blockIdx.x * MLP_BR;
+    const int in0 = a.dims[0], C = a.dims[a.nl];
+    for (int idx = tid; idx < MLP_BR * in0; idx += 256) {
+        const int r = idx / in0, k = idx % in0, row = row0 + r;
+        float v = 0.f;
+        if (row < a.B) v = k < a.d1 ? a.x1[(size_t)row * a.d1 + k] : a.x2[(size_t)row * a.d2 + (k - a.d1)];
+        xin[r][k] = v;
+    }
+    {
+        const int ni = a.dims[0], no = a.dims[1];
+        const float* __restrict__ W = a.W[0];
+        for (int idx = tid; idx < no * ni; idx += 256) wt[(idx % ni) * (no + 1) + idx / ni] = W[idx];
+    }
+    // labels that count (every workgroup counts all of them: an integer, the same in every workgroup)
+    int cnt = 0;
+    for (int i = tid; i < a.B * C; i += 256) cnt += h.t[i] != -1 ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
+    if (lane == 0) redi[wv] = cnt;
+    __syncthreads();
+    const int n_valid = (redi[0] + redi[1]) + (redi[2] + redi[3]);
+    const float inv_n = 1.f / (n_valid > 1 ? (float)n_valid : 1.f);
+    // ---- forward ----
+    for (int l = 0; l < a.nl; ++l) {
+        const int ni = a.dims[l], no = a.dims[l + 1];
+        const float* __restrict__ W = a.W[l];
+        const float* __restrict__ bb = a.b[l];
+        const bool last = l == a.nl - 1;
+        for (int idx = tid; idx < MLP_BR * no; idx += 256) {
+            const int r = idx / no, j = idx % no;
+            float acc = bb ? bb[j] : 0.f;
+            if (l == 0) {
+                const float* x = xin[r];
+                const float* w = wt + j;
+                for (int k = 0; k < ni; ++k) acc += x[k] * w[k * (no + 1)];
+            } else {
+                const float* x = hid[l - 1][r];
+                const float* w = W + (size_t)j * ni;
+                for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
+            }
+            if (!last) acc = acc > 0.f ? acc : 0.f;
+            hid[l][r][j] = acc;
+            if (row0 + r < a.B) a.act[l][(size_t)(row0 + r) * no + j] = acc;
+        }
+        __syncthreads();
+    }
+    // ---- loss of the workgroup's rows, gradient w.r.t. the logits ----
+    float lsum = 0.f;
+    for (int idx = tid; idx < MLP_BR * C; idx += 256) {
+        const int r = idx / C, j = idx % C, row = row0 + r;
+        float g = 0.f;
+        if (row < a.B) {
+            const int ti = h.t[(size_t)row * C + j];
+            if (ti != -1) {
+                const float yi = hid[a.nl - 1][r][j];
+                lsum += (yi > 0.f ? yi : 0.f) + log1pf(expf(-fabsf(yi))) - (float)ti * yi;
+                g = (1.f / (1.f + expf(-yi)) - (float)ti) * inv_n;
+            }
+            h.dy[(size_t)row * C + j] = g;
+        }
+        dcur[0][r][j] = g;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lsum += __shfl_xor(lsum, m);
+    if (lane == 0) redf[wv] = lsum;
+    __syncthreads();
+    if (tid == 0) h.part[blockIdx.x] = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+    // ---- backward down to the input rows ----
+    int cur = 0;
+    for (int l = a.nl - 1; l >= 0; --l) {
+        const int ni = a.dims[l], no = a.dims[l + 1];
+        const float* __restrict__ W = a.W[l];
+        if (l > 0) {
+            for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
+                const int r = idx / ni, k = idx % ni;
+                float acc = 0.f;
+                for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
+                dcur[cur ^ 1][r][k] = hid[l - 1][r][k] > 0.f ? acc : 0.f;
+            }
+        } else {
+            for (int k = tid; k < ni; k += 256) {
+                float acc[MLP_BR];
+#pragma unroll
+                for (int r = 0; r < MLP_BR; ++r) acc[r] = 0.f;
+                for (int j = 0; j < no; ++j) {
+                    const float wv0 = W[(size_t)j * ni + k];
+#pragma unroll
+                    for (int r = 0; r < MLP_BR; ++r) acc[r] += dcur[cur][r][j] * wv0;
+                }
+#pragma unroll
+                for (int r = 0; r < MLP_BR; ++r) {
+                    const int row = row0 + r;
+                    if (row >= a.B) continue;
+                    if (k < a.d1) a.dx1[(size_t)row * a.d1 + k] = acc[r];
+                    else a.dx2[(size_t)row * a.d2 + (k - a.d1)] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- the workgroup that finishes last folds the loss numerators, in workgroup order ----
+    if (tid == 0) {
+        __threadfence();
+        const unsigned tk = atomicAdd(h.ticket, 1u);
+        last_flag = tk == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_flag && tid == 0) {
+        __threadfence();
+        float num = 0.f;
+        for (unsigned w = 0; w < gridDim.x; ++w) num += __hip_atomic_load(h.part + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h.sums[0] = num; h.sums[1] = (float)n_valid;
+        h.loss[0] = num * inv_n;
+        *h.ticket = 0u;
+    }
+}
+
+extern "C" size_t bmp_mlp_sce_ws_floats(int B) { return (size_t)(B + MLP_BR - 1) / MLP_BR; }
+
+// act as bmp_mlp_fwd (the last one: the logits); t [B x dims[nl]] int32; dy [B x dims[nl]]; dx1 / dx2: the gradient of the
+// mean loss w.r.t. the input rows; loss [1], sums [2] as bmp_sce_fwd; part: bmp_mlp_sce_ws_floats(B) floats; ticket: one
+// unsigned that is zero before the call (and zero again when the launch has finished).
+extern "C" int bmp_mlp_sce_fwdbwd(const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                                  const float* const* W, const float* const* b, float* const* act, const int* t, float* dy,
+                                  float* dx1, float* dx2, float* loss, float* sums, float* part, unsigned* ticket,
+                                  hipStream_t st) {
+    MlpArgs a;
+    int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, b, act);
+    if (rc) return rc;
+    BMP_REQUIRE(t && dy && dx1 && (d2 == 0 || dx2) && loss && sums && part && ticket);
+    a.dx1 = dx1; a.dx2 = dx2;
+    HeadArgs h{t, dy, part, ticket, loss, sums};
+    const size_t wt_bytes = (size_t)dims[0] * (dims[1] + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_sce, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 49152);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    BMP_REQUIRE(wt_bytes + 49152 <= 160 * 1024);
+    hipLaunchKernelGGL(k_mlp_sce, dim3((B + MLP_BR - 1) / MLP_BR), dim3(256), wt_bytes, st, a, h);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The weight / bias gradients of bmp_mlp_bwd alone (dy as written by bmp_mlp_sce_fwdbwd), every one multiplied with the device
+// scalar gscale[0] (NULL: 1): per-workgroup partials and their fixed-order fold, all on `st`.
+extern "C" int bmp_mlp_bwd_w(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                             const float* const* W, float* const* act, float* const* dW, float* const* db, const float* gscale,
+                             float* ws, size_t ws_floats, hipStream_t st) {
+    MlpArgs a;
+    int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, nullptr, act);
+    if (rc) return rc;
+    BMP_REQUIRE(dy && dW && ws && ws_floats >= bmp_mlp_bwd_ws_floats(B, nl, dims));
+    const int nwg = (B + MLP_BR - 1) / MLP_BR;
+    MlpRedArgs r; memset(&r, 0, sizeof(r));
+    int off = 0;
+    for (int l = 0; l < nl; ++l) {
+        BMP_REQUIRE(dW[l] != nullptr);
+        r.off[l] = off; r.nw[l] = dims[l + 1] * dims[l]; r.dW[l] = dW[l]; r.db[l] = db ? db[l] : nullptr;
+        off += dims[l + 1] * (dims[l] + 1);
+    }
+    r.off[nl] = off; r.nl = nl; r.slab = ws; r.nslab = nwg; r.stride = off; r.gscale = gscale;
+    a.dy = dy; a.slab = ws; a.slab_stride = off;
+    hipLaunchKernelGGL((k_mlp_bwd<false, true>), dim3(nwg), dim3(256), 0, st, a);
+    BMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((off + 63) / 64), dim3(256), 0, st, r);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -252,7 +252,8 @@ int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const float* X1, 
                        const float* Q2, const float* Z1, const float* Z2, const float* Cbuf, const float* H1,
                        const float* H2, const float* al1, const float* al2, float* dX1, float* dX2, float* dWbT,
                        float* dZW1T, float* dZW2T, float* dzb, float* dwa, float* ws, size_t ws_floats,
-                       bmp_stream_t stream, bmp_stream_t stream_w, const int* row_mol1, const int* row_mol2);
+                       bmp_stream_t stream, bmp_stream_t stream_w, const int* row_mol1, const int* row_mol2,
+                       const float* gscale);
 
 /* ---- BiMPM matching -- models/coattention/bimpm.py:45-199 with aggr = F.sum (train_binary.py:253-256) ----
  * mol_1, mol_2 [B x 3H] for B drug pairs: max-pooling matching, attentive-mean matching and attentive-max matching of every
@@ -338,6 +339,20 @@ size_t bmp_mlp_bwd_ws_floats(int B, int nl, const int* dims);
 int bmp_mlp_bwd(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
                 const float* const* W, float* const* act, float* dx1, float* dx2, float* const* dW, float* const* db,
                 float* ws, size_t ws_floats, bmp_stream_t stream, bmp_stream_t stream_w);
+/* The head of a TRAINING step in one launch -- what chainer_chemistry's Classifier(predictor, lossfun=F.sigmoid_cross_entropy)
+ * does around the link predictor (train_ddi_modify.py:284-286; models/mlp.py:40-45): MLP forward (act as bmp_mlp_fwd, the last
+ * entry = the logits), mean sigmoid cross entropy over the labels t [B x dims[nl]] != -1 (loss [1]; sums [2] = numerator |
+ * count), its gradient dy [B x dims[nl]] and the MLP backward down to the input rows: dx1 / dx2 = d loss / d x for d loss = 1.
+ * part: bmp_mlp_sce_ws_floats(B) floats; ticket: one unsigned, zero before the call and zero again after the launch.
+ * bmp_mlp_bwd_w: the weight / bias gradients from that dy (bmp_mlp_bwd's, without dx), multiplied with the device scalar
+ * gscale[0] (NULL: 1) -- the gradient that arrives at the loss; ws as bmp_mlp_bwd. */
+size_t bmp_mlp_sce_ws_floats(int B);
+int bmp_mlp_sce_fwdbwd(const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims, const float* const* W,
+                       const float* const* b, float* const* act, const int* t, float* dy, float* dx1, float* dx2, float* loss,
+                       float* sums, float* part, unsigned* ticket, bmp_stream_t stream);
+int bmp_mlp_bwd_w(const float* dy, const float* x1, int d1, const float* x2, int d2, int B, int nl, const int* dims,
+                  const float* const* W, float* const* act, float* const* dW, float* const* db, const float* gscale, float* ws,
+                  size_t ws_floats, bmp_stream_t stream);
 int bmp_sce_fwd(const float* y, const int* t, int n, float* loss, float* sums, bmp_stream_t stream);
 int bmp_sce_bwd(const float* y, const int* t, int n, const float* sums, const float* gout, float* dy, bmp_stream_t stream);
 

@@ -242,7 +242,10 @@ def test_readout_taken_off_the_chain_still_gives_the_molecule_vectors():
         y = opt.functional_forward(pb)
     finally:
         model.graph_conv.forward = enc_forward
-    assert seen["off"] is True and opt.plan.state.get("side_used")
+    # (beside the chain = on the forward's second-chain stream, idle once the encoder is through; BMP_READOUT_STREAM=side: on the
+    #  weight-gradient stream)
+    assert seen["off"] is True and (opt.plan.state.get("split_open") or opt.plan.state.get("side_used"))
+    opt.plan.split.join()
     opt.plan.side.join()
     torch.cuda.synchronize()
     assert torch.equal(seen["g"].detach(), g_eager)
