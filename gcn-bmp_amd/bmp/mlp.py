@@ -300,9 +300,13 @@ class MLP(nn.Module):
         """(mean sigmoid cross entropy of the logits against ``t``, logits): the reference's Classifier around this link
         predictor (train_ddi_modify.py:284-286).  On the device, with gradients on, one launch each way (MLPLossFn); otherwise
         ``forward`` followed by ``sigmoid_cross_entropy``."""
-        if x.is_cuda and torch.is_grad_enabled() and self.in_dim is not None and self._kernel_ok() and \
+        ls = self._linears()
+        dims = [self.in_dim] + [l.out_size for l in ls]
+        # (the launch keeps every layer's weights in LDS beside 48 KB of row buffers)
+        fits = self.in_dim is not None and 4 * (dims[0] * (dims[1] + 1) + sum(dims[k + 1] * (dims[k] + 1) for k in range(1, len(ls)))) \
+            <= 160 * 1024 - 49152
+        if x.is_cuda and torch.is_grad_enabled() and fits and self._kernel_ok() and \
                 x.shape[-1] + (0 if x2 is None else x2.shape[-1]) == self.in_dim:
-            ls = self._linears()
             fast = getattr(self, "_fast", None)
             if fast is not None:
                 P, G, state, tape = fast

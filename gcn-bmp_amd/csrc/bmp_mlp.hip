@@ -288,10 +288,19 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
     __shared__ float redf[4];
     __shared__ int redi[4];
     __shared__ int last_flag;
-    extern __shared__ float wt[];                         // first-layer weights, transposed: wt[k * (no + 1) + j]
+    // ALL weights in LDS: layer 0 transposed, wt[k * (no + 1) + j]; the layers behind it as they are, rows padded by one float,
+    // wl[j * (ni + 1) + k].  (Read from global memory inside the layers' loops -- a dependent load per multiply-add, 32 of them
+    // per thread in the walk back to the input rows alone -- the launch took 47 us for its few hundred multiply-adds per row.)
+    extern __shared__ float wt[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int row0 = blockIdx.x * MLP_BR;
     const int in0 = a.dims[0], C = a.dims[a.nl];
+    int woff[MLP_MAXL];
+    {
+        int o = a.dims[0] * (a.dims[1] + 1);
+        woff[0] = 0;
+        for (int l = 1; l < a.nl; ++l) { woff[l] = o; o += a.dims[l + 1] * (a.dims[l] + 1); }
+    }
     for (int idx = tid; idx < MLP_BR * in0; idx += 256) {
         const int r = idx / in0, k = idx % in0, row = row0 + r;
         float v = 0.f;
@@ -302,6 +311,12 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
         const int ni = a.dims[0], no = a.dims[1];
         const float* __restrict__ W = a.W[0];
         for (int idx = tid; idx < no * ni; idx += 256) wt[(idx % ni) * (no + 1) + idx / ni] = W[idx];
+    }
+    for (int l = 1; l < a.nl; ++l) {
+        const int ni = a.dims[l], no = a.dims[l + 1];
+        const float* __restrict__ W = a.W[l];
+        float* wl = wt + woff[l];
+        for (int idx = tid; idx < no * ni; idx += 256) wl[(idx / ni) * (ni + 1) + idx % ni] = W[idx];
     }
     // labels that count (every workgroup counts all of them: an integer, the same in every workgroup)
     int cnt = 0;
@@ -315,7 +330,6 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
     // ---- forward ----
     for (int l = 0; l < a.nl; ++l) {
         const int ni = a.dims[l], no = a.dims[l + 1];
-        const float* __restrict__ W = a.W[l];
         const float* __restrict__ bb = a.b[l];
         const bool last = l == a.nl - 1;
         for (int idx = tid; idx < MLP_BR * no; idx += 256) {
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
                 for (int k = 0; k < ni; ++k) acc += x[k] * w[k * (no + 1)];
             } else {
                 const float* x = hid[l - 1][r];
-                const float* w = W + (size_t)j * ni;
+                const float* w = wt + woff[l] + j * (ni + 1);
                 for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
             }
             if (!last) acc = acc > 0.f ? acc : 0.f;
@@ -361,21 +375,22 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
     int cur = 0;
     for (int l = a.nl - 1; l >= 0; --l) {
         const int ni = a.dims[l], no = a.dims[l + 1];
-        const float* __restrict__ W = a.W[l];
         if (l > 0) {
+            const float* wl = wt + woff[l];
             for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
                 const int r = idx / ni, k = idx % ni;
                 float acc = 0.f;
-                for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
+                for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * wl[j * (ni + 1) + k];
                 dcur[cur ^ 1][r][k] = hid[l - 1][r][k] > 0.f ? acc : 0.f;
             }
         } else {
-            for (int k = tid; k < ni; k += 256) {
+            for (int k = tid; k < ni; k += 256) {         // a thread owns input column k for all rows of the workgroup
                 float acc[MLP_BR];
 #pragma unroll
                 for (int r = 0; r < MLP_BR; ++r) acc[r] = 0.f;
+                const float* w = wt + k * (no + 1);
                 for (int j = 0; j < no; ++j) {
-                    const float wv0 = W[(size_t)j * ni + k];
+                    const float wv0 = w[j];
 #pragma unroll
                     for (int r = 0; r < MLP_BR; ++r) acc[r] += dcur[cur][r][j] * wv0;
                 }
@@ -423,7 +438,8 @@ extern "C" int bmp_mlp_sce_fwdbwd(const float* x1, int d1, const float* x2, int 
     BMP_REQUIRE(t && dy && dx1 && (d2 == 0 || dx2) && loss && sums && part && ticket);
     a.dx1 = dx1; a.dx2 = dx2;
     HeadArgs h{t, dy, part, ticket, loss, sums};
-    const size_t wt_bytes = (size_t)dims[0] * (dims[1] + 1) * sizeof(float);
+    size_t wt_bytes = (size_t)dims[0] * (dims[1] + 1) * sizeof(float);
+    for (int l = 1; l < nl; ++l) wt_bytes += (size_t)dims[l + 1] * (dims[l] + 1) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_mlp_sce, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 49152);
