@@ -53,9 +53,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
             const float* x = buf[cur][r];
             if (l == 0) {
                 const float* w = wt + j;
+#pragma unroll 8
                 for (int k = 0; k < ni; ++k) acc += x[k] * w[k * (no + 1)];
             } else {
                 const float* w = W + (size_t)j * ni;      // <= 64 x 64: cache resident
+#pragma unroll 8
                 for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
             }
             if (!last) acc = acc > 0.f ? acc : 0.f;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
             float xk[MLP_BR];
 #pragma unroll
             for (int r = 0; r < MLP_BR; ++r) xk[r] = l == 0 ? xin[r][k] : hid[l - 1][r][k];
+#pragma unroll 8
             for (int j = 0; j < no; ++j) {
                 float acc = 0.f;
 #pragma unroll
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
             for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
                 const int r = idx / ni, k = idx % ni;
                 float acc = 0.f;
+#pragma unroll 8
                 for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * W[(size_t)j * ni + k];
                 dcur[cur ^ 1][r][k] = hid[l - 1][r][k] > 0.f ? acc : 0.f;
             }
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
                 float acc[MLP_BR];
 #pragma unroll
                 for (int r = 0; r < MLP_BR; ++r) acc[r] = 0.f;
+#pragma unroll 8
                 for (int j = 0; j < no; ++j) {
                     const float wv = W[(size_t)j * ni + k];
 #pragma unroll
@@ -338,10 +343,12 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
             if (l == 0) {
                 const float* x = xin[r];
                 const float* w = wt + j;
+#pragma unroll 8
                 for (int k = 0; k < ni; ++k) acc += x[k] * w[k * (no + 1)];
             } else {
                 const float* x = hid[l - 1][r];
                 const float* w = wt + woff[l] + j * (ni + 1);
+#pragma unroll 8
                 for (int k = 0; k < ni; ++k) acc += x[k] * w[k];
             }
             if (!last) acc = acc > 0.f ? acc : 0.f;
@@ -380,6 +387,7 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
             for (int idx = tid; idx < MLP_BR * ni; idx += 256) {
                 const int r = idx / ni, k = idx % ni;
                 float acc = 0.f;
+#pragma unroll 8
                 for (int j = 0; j < no; ++j) acc += dcur[cur][r][j] * wl[j * (ni + 1) + k];
                 dcur[cur ^ 1][r][k] = hid[l - 1][r][k] > 0.f ? acc : 0.f;
             }
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(256) void k_mlp_sce(MlpArgs a, HeadArgs h) {
 #pragma unroll
                 for (int r = 0; r < MLP_BR; ++r) acc[r] = 0.f;
                 const float* w = wt + k * (no + 1);
+#pragma unroll 8
                 for (int j = 0; j < no; ++j) {
                     const float wv0 = w[j];
 #pragma unroll
