@@ -88,8 +88,8 @@ CONFIGS = {
 
 KERNEL_NAMES = {16: "k_rowgemm / k_rowgemm_db (fp32 MFMA row GEMM)", 17: "k_rowgemm_multi", 18: "k_readout_tile_fwd",
                 32: "k_wgrad_lds<false> (fp32 MFMA weight-gradient GEMM)", 33: "k_wgrad_lds<true>",
-                34: "k_wgrad_lds<false> one-hot (embedding gradient)", 35: "k_wgrad (direct)", 36: "k_wgrad_lds_multi<0>",
-                37: "k_wgrad_lds_multi<1> (fp32 MFMA weight-gradient GEMM of a fused step: o1 | o2 | dUcT in one launch)",
+                34: "k_wgrad_lds<false> one-hot (embedding gradient)", 35: "k_wgrad (direct)", 36: "k_wgrad_dma_multi<0>",
+                37: "k_wgrad_dma_multi<1> (fp32 MFMA weight-gradient GEMM of a fused step: o1 | o2 | dUcT in one launch, stages by LDS-DMA)",
                 64: "k_coattn_fwd", 65: "k_coattn_bwd", 80: "k_ggnn_step_fwd<D, false>", 81: "k_ggnn_step_fwd<D, true>",
                 82: "k_relgcn_layer_fwd", 83: "k_ggnn_step_fwd<D, .., TS = true> (all T propagation steps of a tile in one launch)",
                 96: "k_ggnn_step_bwd<D, false>", 97: "k_ggnn_step_bwd<D, true>",
@@ -100,7 +100,7 @@ CLASS_NAMES = {1: "row GEMMs", 2: "weight-gradient GEMMs", 3: "gathers", 4: "co-
 # arguments behind the prefix differ with the tile layout (whole tiles / tile table) and, for the row GEMM, with its epilogue;
 # a key's traffic is the launch-weighted mean over the profile's kernels that carry the prefix
 PMC_NAMES = {16: ("k_rowgemm<", "k_rowgemm_db<", "k_rowgemm_lds<"), 32: ("k_wgrad_lds<false>",), 33: ("k_wgrad_lds<true>",),
-             36: ("k_wgrad_lds_multi<0>",), 37: ("k_wgrad_lds_multi<1>",), 80: ("k_ggnn_step_fwd<{D}, false",),
+             36: ("k_wgrad_dma_multi<0>", "k_wgrad_lds_multi<0>"), 37: ("k_wgrad_dma_multi<1>", "k_wgrad_lds_multi<1>"), 80: ("k_ggnn_step_fwd<{D}, false",),
              81: ("k_ggnn_step_fwd<{D}, true",), 96: ("k_ggnn_step_bwd<{D}, false",), 97: ("k_ggnn_step_bwd<{D}, true",),
              82: ("k_relgcn_layer_fwd<{D}",), 83: ("k_ggnn_step_fwd<{D}",), 98: ("k_relgcn_layer_bwd<{D}",), 17: ("k_rowgemm_multi",), 18: ("k_readout_tile_fwd<{D}",)}
 

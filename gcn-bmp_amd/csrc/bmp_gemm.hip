@@ -787,7 +787,167 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
 // own row count, split size and slab).  For problems that are a launch of 1-2 tiles x ~128 splits each: back to back
 // every one of them lasts one workgroup's latency, side by side they share it.  ONE staging area: an LDS array per
 // instantiated body would halve the workgroups per CU.
-struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; int grouped, smax; };
+// The same 128 x 128 tile with its stages filled by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing
+// through registers): stages of WD_RS = 16 rows, WD_NS = 3 of them in LDS, two in flight behind the one that feeds the MFMAs;
+// counted vmcnt + one raw s_barrier per stage.  Against the register-staged body: no staging registers, no ds_write phase
+// behind the MFMAs of a stage (the wait for the loads sat right in front of it), 48 KB of LDS instead of 67.5 (three
+// workgroups per CU).  Same products in the same order: bit for bit the register-staged result (stand-alone harness
+// tools/wgrad_bench.hip, the 11-tile shape of a fused step: 218 -> 175 us).  Stage layout: X [16 x 128] | dY [16 x 128] |
+// X2 [16 x 128] (only in launches that have an X2 problem); rows are 128 floats without padding (a DMA writes a wave's 64
+// pieces back to back), which the fragment reads -- 32 consecutive floats of a row per half-wave -- take without conflicts.
+#define WD_RS 16
+#define WD_NS 3
+template <bool HAS_X2>
+__device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, int bx, int by, int bz, float* sm, int ssz) {
+    constexpr int XSZ = WD_RS * 128;
+    constexpr int NI = WD_RS / 8;                    // DMA instructions per wave, operand and stage (a wave moves two rows each)
+    constexpr int NLD = NI * (HAS_X2 ? 3 : 2);       // loads per lane and stage
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int i_tile = bx * 128, j_tile = by * 128;
+    const int s = bz;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) / WD_RS;
+    const int c4 = tid & 31, rr = tid >> 5;          // column sums: this thread's four columns of the rows rr, rr + 8 of a stage
+    const int coly = j_tile + 4 * c4;
+    const bool oky = coly < a.Nn;
+    const bool do_cs = want_cs != 0 && bx == 0;
+    const bool do_w = do_cs && a.wrow != nullptr && j_tile >= a.w_col0;
+    const int Krows = a.K + (want_cs ? 1 : 0) + (a.wrow ? 4 : 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 csw[4] = {csum, csum, csum, csum};
+
+    // per-lane sources: columns beyond the matrix read a valid address of the same row instead (their products are never stored)
+    int xcol = i_tile + 4 * l31;
+    if (xcol > a.K - 4) xcol = a.K - 4;
+    int ycol = j_tile + 4 * l31;
+    if (ycol > a.Nn - 4) ycol = a.Nn - 4;
+    ycol += (ycol >= a.skip_at ? a.skip_n : 0);        // physical dY column
+    const float* xsrc = a.X + (size_t)(r_begin + 2 * w + hi) * a.ldx + xcol;
+    const float* x2src = HAS_X2 ? a.X2 + (size_t)(r_begin + 2 * w + hi) * a.ldx2 + xcol : nullptr;
+    const float* ysrc = a.dY + (size_t)(r_begin + 2 * w + hi) * a.ldy + ycol;
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef const __attribute__((address_space(1))) float glb_f;
+    // the rows' four weights (weighted column sums) ride along as one more piece of the stage, moved by wave 0 and issued FIRST:
+    // the counted wait below leaves the youngest NLD loads of a wave outstanding, i.e. the next stage's X / dY / X2 pieces
+    const int WOFF = (HAS_X2 ? 3 : 2) * XSZ;
+    const float* wsrc = do_w ? a.wrow + (size_t)(r_begin + (lane & 15)) * 4 : nullptr;
+#define WD_ISSUE(st)                                                                                                    \
+    {                                                                                                                   \
+        float* base = sm + ((st) % WD_NS) * ssz;                                                                        \
+        const size_t ro = (size_t)(st) * WD_RS;                                                                         \
+        if (do_w && w == 0 && lane < WD_RS)                                                                             \
+            __builtin_amdgcn_global_load_lds((glb_f*)(wsrc + ro * 4), (lds_f*)(base + WOFF), 16, 0, 0);                 \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                \
+            __builtin_amdgcn_global_load_lds((glb_f*)(xsrc + (ro + 8 * i) * a.ldx), (lds_f*)(base + (2 * w + 8 * i) * 128), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_f*)(ysrc + (ro + 8 * i) * a.ldy), (lds_f*)(base + XSZ + (2 * w + 8 * i) * 128), 16, 0, 0); \
+            if (HAS_X2)                                                                                                 \
+                __builtin_amdgcn_global_load_lds((glb_f*)(x2src + (ro + 8 * i) * a.ldx2), (lds_f*)(base + 2 * XSZ + (2 * w + 8 * i) * 128), 16, 0, 0); \
+        }                                                                                                               \
+    }
+#pragma unroll
+    for (int p = 0; p < WD_NS - 1; ++p)
+        if (p < nst) WD_ISSUE(p)
+    for (int st = 0; st < nst; ++st) {
+        // stage st has landed once at most the loads of the stages issued behind it are outstanding (loads complete in order)
+        if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // every wave's pieces of the stage are in LDS; stage st - 1 has been read
+        if (st + WD_NS - 1 < nst) WD_ISSUE(st + WD_NS - 1)
+        const float* XS = sm + (st % WD_NS) * ssz;
+        const float* YS = XS + XSZ;
+        const float* X2S = XS + 2 * XSZ;
+        const float* WS = XS + WOFF;
+        if (do_cs) {                                 // column sums (and the weighted ones), in the register-staged body's order
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const f32x4 yr = *(const f32x4*)(YS + (rr + 8 * i) * 128 + 4 * c4);
+                csum += yr;
+                if (do_w) {
+                    const f32x4 wr4 = *(const f32x4*)(WS + (rr + 8 * i) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) csw[e] += wr4[e] * yr;
+                }
+            }
+        }
+        float av[2][2][4], bv[2][2][4];
+#define WD_FRAG(slot, k0)                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                     \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                                 \
+            av[slot][m][t] = XS[((k0) + 4 * hi + t) * 128 + wm * 64 + m * 32 + l31];                                    \
+            if (HAS_X2) av[slot][m][t] *= X2S[((k0) + 4 * hi + t) * 128 + wm * 64 + m * 32 + l31];                      \
+        }                                                                                                               \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) bv[slot][n][t] = YS[((k0) + 4 * hi + t) * 128 + wn * 64 + n * 32 + l31]; \
+    }
+        WD_FRAG(0, 0)
+#pragma unroll
+        for (int ks = 0; ks < WD_RS / 8; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < WD_RS / 8) { WD_FRAG(cur ^ 1, (ks + 1) * 8) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t], bv[cur][n][t], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WD_FRAG
+    }
+#undef WD_ISSUE
+
+    float* slab = a.slab + (size_t)s * Krows * a.Nn;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = i_tile + wm * 64 + m * 32 + bmp_acc_row(reg, lane);
+                if (i < a.K && j < a.Nn) slab[(size_t)i * a.Nn + j] = acc[m][n][reg];
+            }
+        }
+    if (do_cs) {        // column sums of this split's dY rows: reduce the 8 row groups through LDS
+        __syncthreads();                             // the last stage has been read by every wave
+        f32x4* red = (f32x4*)sm;
+        red[rr * 32 + c4] = csum;
+        __syncthreads();
+        if (rr == 0 && oky) {
+            f32x4 t = red[c4];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += red[g * 32 + c4];
+            *(f32x4*)(slab + (size_t)a.K * a.Nn + coly) = t;
+        }
+        if (do_w) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __syncthreads();
+                red[rr * 32 + c4] = csw[e];
+                __syncthreads();
+                if (rr == 0 && oky) {
+                    f32x4 t = red[c4];
+#pragma unroll
+                    for (int g = 1; g < 8; ++g) t += red[g * 32 + c4];
+                    *(f32x4*)(slab + (size_t)(a.K + 1 + e) * a.Nn + coly) = t;
+                }
+            }
+        }
+    }
+}
+
+struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; int grouped, smax, ssz; };
 // STEP = 1: the launch of bmp_launch_wgrad_fused (same code; a separate symbol so that profiles tell the fused step
 // weight gradients from the co-attention's small three-problem launch)
 template <int STEP>
@@ -814,6 +974,55 @@ __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
     if (bz >= m.S[p]) return;
     if (m.p[p].X2) wgrad_lds_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, XS, YS);
     else wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, XS, YS);
+}
+
+// The same launch on the LDS-DMA body (wgrad_dma_body); m.ssz = floats of one stage in the dynamic LDS block.
+template <int STEP>
+__global__ __launch_bounds__(256) void k_wgrad_dma_multi(WGKMulti m) {
+    extern __shared__ __attribute__((aligned(16))) float wd_sm[];
+    int by, bz;
+    if (m.grouped) {          // see k_wgrad_lds_multi
+        const int T = m.ty0[3], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
+        if (slot < G * T) { bz = xcd * G + slot / T; by = slot % T; }
+        else {
+            const int r = (slot - G * T) * 8 + xcd;
+            if (r >= (m.smax - 8 * G) * T) return;
+            bz = 8 * G + r / T; by = r % T;
+        }
+    } else { by = blockIdx.y; bz = blockIdx.z; }
+    const int p = by >= m.ty0[2] ? 2 : (by >= m.ty0[1] ? 1 : 0);
+    if (bz >= m.S[p]) return;
+    if (m.p[p].X2) wgrad_dma_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
+    else wgrad_dma_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
+}
+
+// Launches k_wgrad_dma_multi<STEP> when every problem of the launch can take the DMA body (whole 16-byte pieces in range:
+// K and Nn at least 4 and multiples of 4 -- wgrad_use_lds --, no one-hot operand), else k_wgrad_lds_multi<STEP>.
+// BMP_WGRAD_DMA=0: always the register-staged kernel.
+template <int STEP>
+static int wgrad_multi_launch(WGKMulti& m, int n, const dim3& grid, hipStream_t st) {
+    static const int on = [] { const char* e = getenv("BMP_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+    bool ok = on != 0, x2 = false;
+    for (int p = 0; p < n; ++p) {
+        if (m.S[p] == 0) continue;
+        ok = ok && !m.p[p].onehot && m.p[p].K >= 4 && m.p[p].Nn >= 4 && (m.p[p].rows_per_split % WD_RS) == 0 && (m.p[p].N % WD_RS) == 0;
+        x2 = x2 || m.p[p].X2 != nullptr;
+    }
+    if (!ok) {
+        hipLaunchKernelGGL((k_wgrad_lds_multi<STEP>), grid, dim3(256), 0, st, m);
+        return 0;
+    }
+    m.ssz = WD_RS * 128 * (x2 ? 3 : 2) + WD_RS * 4;          // + the rows' four weights
+    const size_t lds = (size_t)WD_NS * m.ssz * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_dma_multi<STEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           WD_NS * (WD_RS * 128 * 3 + WD_RS * 4) * (int)sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_wgrad_dma_multi<STEP>), grid, dim3(256), lds, st, m);
+    return 0;
 }
 
 // Grid of a three-problem launch: XCD-grouped (see the kernel) when the work fits the chip's 512 slots in one round and there
@@ -936,6 +1145,8 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
             BmpProfScope prof(BMP_KCLS_WGRAD, a.onehot ? 0.0 : 2.0 * a.N * (double)a.K * a.Nn,
                               4.0 * a.N * ((a.onehot ? 1.0 : (double)a.K) + a.Nn), st,
                               a.onehot ? BMP_KID_WGRAD_ONEHOT : (a.X2 ? BMP_KID_WGRAD_X2 : BMP_KID_WGRAD));
+            // (register-staged body: on the single-problem launches of the d = 256 configuration -- K = 256, 8-14 column tiles --
+            //  the LDS-DMA body measured 1.5 % slower for the step; the one-hot operand is made in registers anyway)
             if (a.X2) hipLaunchKernelGGL((k_wgrad_lds<true>), grid, dim3(256), 0, st, k, want_cs);
             else hipLaunchKernelGGL((k_wgrad_lds<false>), grid, dim3(256), 0, st, k, want_cs);
         }
@@ -1019,7 +1230,8 @@ int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
     {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, BMP_KID_WGRAD_MULTI);
         const dim3 grid = wgrad_grouped_grid(m, smax);
-        hipLaunchKernelGGL((k_wgrad_lds_multi<0>), grid, dim3(256), 0, st, m);
+        const int rc = wgrad_multi_launch<0>(m, n, grid, st);
+        if (rc) return rc;
     }
     BMP_LAUNCH_CHECK();
     for (int p = 0; p < n; ++p) {
@@ -1105,7 +1317,8 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
     if (m.ty0[3] > 0) {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, kid);
         const dim3 grid = wgrad_grouped_grid(m, smax);
-        hipLaunchKernelGGL((k_wgrad_lds_multi<1>), grid, dim3(256), 0, st, m);
+        const int rc = wgrad_multi_launch<1>(m, n, grid, st);
+        if (rc) return rc;
     }
     BMP_LAUNCH_CHECK();
     if (rb > 0) hipLaunchKernelGGL(k_reduce_multi, dim3(rb), dim3(256), 0, st, r);

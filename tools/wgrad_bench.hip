@@ -298,6 +298,84 @@ static void launch_dmaw(const WGKArgs& a, int tiles, int S) {
     hipLaunchKernelGGL(k_wg_dmaw, dim3(1, (a.Nn + 255) / 256, S), dim3(512), lds, 0, a);
 }
 
+// variant: the product's 128 x 128 tile / 256 threads / two workgroups per CU, stages of RS rows filled by LDS-DMA NS - 1 stages
+// ahead (no staging registers, no ds_write phase); counted vmcnt + raw s_barrier, one barrier per stage
+template <int RS, int NS>
+__global__ __launch_bounds__(256) void k_wg_dma(WGKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int XSZ = RS * 128, SSZ = 2 * XSZ;
+    constexpr int NI = RS / 8;                     // DMA instructions per wave, operand and stage (a wave moves 2 rows each)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int j_tile = blockIdx.y * 128;
+    const int s = blockIdx.z;
+    const int r_begin = s * a.rows_per_split;
+    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
+    const int nst = (r_end - r_begin) / RS;
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    const float* xsrc = a.X + (size_t)(r_begin + 2 * w + hi) * a.ldx + 4 * l31;
+    const float* ysrc = a.dY + (size_t)(r_begin + 2 * w + hi) * a.ldy + j_tile + 4 * l31;
+    typedef __attribute__((address_space(3))) float lds_f;
+    typedef const __attribute__((address_space(1))) float glb_f;
+#define DM_ISSUE(st)                                                                                         \
+    {                                                                                                        \
+        float* base = sm + ((st) % NS) * SSZ;                                                                \
+        const size_t ro = (size_t)(st) * RS;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                     \
+            __builtin_amdgcn_global_load_lds((glb_f*)(xsrc + (ro + 8 * i) * a.ldx), (lds_f*)(base + (2 * w + 8 * i) * 128), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_f*)(ysrc + (ro + 8 * i) * a.ldy), (lds_f*)(base + XSZ + (2 * w + 8 * i) * 128), 16, 0, 0); \
+        }                                                                                                    \
+    }
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) if (p < nst) DM_ISSUE(p)
+    for (int st = 0; st < nst; ++st) {
+        // the oldest stage in flight has landed when at most (stages still behind it) * 2 * NI loads are outstanding
+        const int behind = (nst - 1 - st) < (NS - 2) ? (nst - 1 - st) : (NS - 2);
+        if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NI) : "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + NS - 1 < nst) DM_ISSUE(st + NS - 1)
+        const float* XS = sm + (st % NS) * SSZ;
+        const float* YS = XS + XSZ;
+        float av[2][2][4], bv[2][2][4];
+#define MFRAG(slot, k0)                                                                            \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) av[slot][m][t] = XS[((k0) + 4 * hi + t) * 128 + wm * 64 + m * 32 + l31]; \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) bv[slot][n][t] = YS[((k0) + 4 * hi + t) * 128 + wn * 64 + n * 32 + l31]; \
+    }
+        MFRAG(0, 0)
+#pragma unroll
+        for (int ks = 0; ks < RS / 8; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < RS / 8) { MFRAG(cur ^ 1, (ks + 1) * 8) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = bmp_mfma(av[cur][m][t], bv[cur][n][t], acc[m][n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* slab = a.slab + (size_t)s * a.K * a.Nn;
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) {
+            const int j = j_tile + wn * 64 + n * 32 + l31;
+            if (j < a.Nn)
+                for (int reg = 0; reg < 16; ++reg) slab[(size_t)(wm * 64 + m * 32 + bmp_acc_row(reg, lane)) * a.Nn + j] = acc[m][n][reg];
+        }
+}
+template <int RS, int NS>
+static void launch_dma(const WGKArgs& a, int tiles, int S) {
+    const size_t lds = (size_t)NS * 2 * RS * 128 * 4;
+    hipFuncSetAttribute((const void*)k_wg_dma<RS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_wg_dma<RS, NS>), dim3(1, tiles, S), dim3(256), lds, 0, a);
+}
+
 static float run_k(void (*launch)(const WGKArgs&, int, int), const WGKArgs& a, int tiles, int S, int reps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -340,7 +418,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(dY, h.data(), (size_t)N * Nn * 4, hipMemcpyHostToDevice);
     hipMemcpy(X, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
-    const int splits[] = {512 / tiles, 256 / tiles, 1024 / tiles};
+    const int splits[] = {512 / tiles, 768 / tiles, 640 / tiles};
     for (int si = 0; si < 3; ++si) {
         int S = splits[si];
         int rps = ((N + S - 1) / S + 31) & ~31;
@@ -358,6 +436,22 @@ int main(int argc, char** argv) {
         printf("  MFMA only       %7.1f us\n", run<6>(a, tiles, S, 20));
         printf("  loads only      %7.1f us\n", run<5>(a, tiles, S, 20));
         printf("  ring (2 stages) %7.1f us\n", run_k(launch_ring, a, tiles, S, 20));
+        printf("  DMA 32 rows x 2 %7.1f us\n", run_k(launch_dma<32, 2>, a, tiles, S, 20));
+        printf("  DMA 16 rows x 4 %7.1f us\n", run_k(launch_dma<16, 4>, a, tiles, S, 20));
+        printf("  DMA 16 rows x 3 %7.1f us\n", run_k(launch_dma<16, 3>, a, tiles, S, 20));
+        printf("  DMA 8 rows x 8  %7.1f us\n", run_k(launch_dma<8, 8>, a, tiles, S, 20));
+        {   // check the 16 x 4 form against the plain kernel
+            std::vector<float> r0((size_t)K * Nn), r1((size_t)K * Nn), tmp((size_t)K * Nn);
+            for (int form = 0; form < 2; ++form) {
+                if (form == 0) hipLaunchKernelGGL((k_wg<0>), dim3(1, tiles, S), dim3(256), 0, 0, a); else launch_dma<16, 4>(a, tiles, S);
+                hipDeviceSynchronize();
+                std::vector<float>& r = form ? r1 : r0;
+                std::fill(r.begin(), r.end(), 0.f);
+                for (int q = 0; q < S; ++q) { hipMemcpy(tmp.data(), slab + (size_t)q * K * Nn, tmp.size() * 4, hipMemcpyDeviceToHost); for (size_t e = 0; e < tmp.size(); ++e) r[e] += tmp[e]; }
+            }
+            double md = 0, mx = 0; for (size_t e = 0; e < r0.size(); ++e) { md = fmax(md, fabs((double)r0[e] - r1[e])); mx = fmax(mx, fabs((double)r0[e])); }
+            printf("  DMA 16 x 4 vs plain: max diff %.3e (scale %.3e)\n", md, mx);
+        }
         {
             const int wt = (Nn + 255) / 256;
             int Sw = 256 / wt; int rw = ((N + Sw - 1) / Sw + 31) & ~31; Sw = (N + rw - 1) / rw;
