@@ -76,3 +76,19 @@ def test_link_predictors_match_oracle(kind, fp, C, hidden):
     close(b.grad, x2.grad, "dx2")
     for name, gr in grad_dict(lp).items():
         close(gr, p[name].grad, f"grad {name}")
+
+
+def test_classifier_form_of_the_mlp_on_host_tensors_is_forward_plus_loss():
+    """MLP.forward_loss (the reference's Classifier around the link predictor, train_ddi_modify.py:284-286) on host tensors
+    takes the plain ops: the same loss and logits as forward + sigmoid_cross_entropy, labels of -1 left out."""
+    import torch
+    from bmp.mlp import MLP, sigmoid_cross_entropy
+    torch.manual_seed(0)
+    mlp = MLP(3, (32, 16), in_dim=24)
+    g1, g2 = torch.randn(7, 12, requires_grad=True), torch.randn(7, 12, requires_grad=True)
+    t = torch.randint(-1, 2, (7, 3), dtype=torch.int32)
+    loss, y = mlp.forward_loss(g1, g2, t)
+    y0 = mlp(g1, g2)
+    assert torch.equal(y, y0) and torch.equal(loss, sigmoid_cross_entropy(y0, t))
+    loss.backward()
+    assert g1.grad is not None and torch.isfinite(g1.grad).all()
