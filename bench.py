@@ -19,7 +19,9 @@ Rank 0 prints ONE JSON line:
   predict       forward only, under no-backprop: the evaluation callers' predict (eval_coattention.py:103-124)
   dedup         every distinct molecule of a step encoded once (SURVEY.md 8(d) caveat): reported beside `value`, never instead
   other_configs the default (c2) run also times c3 and c4 for 20 steps each, with their dominant kernel's roofline fraction
-  roofline      the dominant kernel and its class, HIP events around every launch, measured in this run
+  roofline      the dominant kernel and its class: durations from HIP events around every launch, measured in this run;
+                `traffic` (HBM bytes per launch) is NOT measured in this run -- PMC counters need rocprofv3 -- but quoted from
+                the committed profile named in `traffic_source` (same library version, config and kernel), null without one
   cpu_baseline  the oracle (dense restatement) on the host cores: same model, batch 32; more: C1 and batch 256
 """
 import argparse
@@ -385,7 +387,7 @@ def main():
             c_e = entry([k for k in kern if k // 16 == cls], CLASS_NAMES.get(cls, str(cls)))
             # HBM bytes per launch of that kernel: PMC counters (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 --pmc passes of
             # this command, committed under profiles/); taken only from a profile of THIS library version, config and kernel
-            traffic = None
+            traffic = traffic_source = None
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
                 try:
                     pmc = json.load(open(path))
@@ -400,9 +402,15 @@ def main():
                     nl = sum(v["launches"] for v in hits)
                     traffic = round(sum((2.0 * v["FETCH_SIZE_per_launch"] + v["WRITE_SIZE_per_launch"]) * v["launches"] for v in hits)
                                     / max(nl, 1) * 1024)
+                    traffic_source = dict(file=os.path.relpath(path, ROOT), bmp_version=pmc.get("_bmp_version"),
+                                          how="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                                              "2 x FETCH + WRITE per launch; replayed, not measured in this run")
                     break
+            if traffic is None:
+                print(f"[bench] no profiles/r*_pmc_hbm_traffic.json for bmp_version {L.bmp_version()} / {self.name} / "
+                      f"{KERNEL_NAMES.get(top, top)}: roofline.traffic is null", file=sys.stderr)
             return dict(bound="mfma", achieved=k_e["achieved"], peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=k_e["frac"],
-                        traffic=traffic, **{k: v for k, v in k_e.items() if k not in ("achieved", "frac")}, kernel_class=c_e,
+                        traffic=traffic, traffic_source=traffic_source, **{k: v for k, v in k_e.items() if k not in ("achieved", "frac")}, kernel_class=c_e,
                         per_kernel_ms_per_step={KERNEL_NAMES.get(k, str(k)): round(v["ms"], 4) for k, v in
                                                 sorted(kern.items(), key=lambda kv: -kv[1]["ms"])},
                         measured=f"HIP events around every launch of every instrumented kernel, {n_prof} steps after the timed "

@@ -175,6 +175,7 @@ class PNieFn(Function):
         L = _lib.lib()
         dev = X1.device
         ctx.state = state
+        ctx.takes_head_gscale = state is not None      # bmp.mlp.MLPLossFn may leave the loss-gradient factor in ``state`` for this node
         ctx.rm = (rm1, rm2) if (rm1 is not None and rm2 is not None) else (None, None)      # row -> molecule maps (dead rows)
         B, T1, T2 = meta["B"], meta["T1"], meta["T2"]
         ZC = L.bmp_coattn_zcols(o, H)

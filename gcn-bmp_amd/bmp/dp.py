@@ -180,6 +180,11 @@ class FlatAdam:
         g = self._leaf.grad
         self._leaf = None
         if self.plan is not None:
+            if self.plan.state.pop("head_gscale", None) is not None:
+                # MLPLossFn.backward handed the factor arriving at the loss to the co-attention node, whose backward did not
+                # run (backward(inputs=...) past it, a frozen co-attention): the rows' gradients went on unscaled
+                raise RuntimeError("the loss-gradient factor left for the co-attention's backward was never consumed; "
+                                   "call loss.backward() through the whole model or use functional_forward + model.loss")
             # one launch: (+)= the planned modules' parameter gradients; when autograd carried none (every parameter is the
             # plan's), that launch writes the whole buffer and no zero-fill precedes it
             self.grad = g if g is not None else torch.empty_like(self.flat)

@@ -84,9 +84,11 @@ class MLPFn(Function):
 _TICKETS = {}
 
 
-def _ticket(device) -> torch.Tensor:
-    """The zero word of bmp_mlp_sce_fwdbwd (zero before every launch, put back to zero by the launch), one per device."""
-    k = (device.type, device.index)
+def _ticket(device, stream_handle) -> torch.Tensor:
+    """The zero word of bmp_mlp_sce_fwdbwd (zero before every launch, put back to zero by the launch): one per (device,
+    STREAM).  Launches on one stream run one behind the other, so they can share the word; two head launches in flight on
+    different streams of a device (a second model, training beside evaluation) each fold on their own."""
+    k = (device.type, device.index, int(stream_handle or 0))
     if k not in _TICKETS:
         _TICKETS[k] = torch.zeros(1, dtype=torch.int32, device=device)
     return _TICKETS[k]
@@ -122,8 +124,9 @@ class MLPLossFn(Function):
         dy, dx = f(B, dims[-1]), f(B * (d1 + d2))
         dx1, dx2 = dx[:B * d1].view(B, d1), (dx[B * d1:].view(B, d2) if d2 else None)
         loss, sums, part = f(()), f(2), f(max(int(L.bmp_mlp_sce_ws_floats(B)), 1))
+        st = stream()
         check(L.bmp_mlp_sce_fwdbwd(ptr(x1), d1, ptr(x2), d2, B, nl, cd, _parr(Ws), _parr(bs), _parr(acts), ptr(t), ptr(dy),
-                                   ptr(dx1), ptr(dx2), ptr(loss), ptr(sums), ptr(part), ptr(_ticket(dev)), stream()),
+                                   ptr(dx1), ptr(dx2), ptr(loss), ptr(sums), ptr(part), ptr(_ticket(dev, st.value)), st),
               "bmp_mlp_sce_fwdbwd")
         ctx.kept = (x1, x2, Ws, acts, dy, dx, dx1, dx2)
         ctx.meta = (nl, dims, [b is not None for b in bs], G, state)
@@ -314,7 +317,10 @@ class MLP(nn.Module):
                 # both input blocks straight out of ONE planned co-attention node: that node's backward takes the factor that
                 # arrives at the loss (a device scalar) into its pair kernels, instead of a launch that scales the rows here
                 fn1, fn2 = getattr(x, "grad_fn", None), getattr(x2, "grad_fn", None)
-                direct = fn1 is not None and fn1 is fn2 and type(fn1).__name__ == "PNieFnBackward" and state is not None
+                # (the node says so itself -- PNieFn.forward sets ``takes_head_gscale`` -- and must hold the SAME plan state this
+                #  module hands the factor through; FlatAdam.collect_grads checks that the factor was consumed)
+                direct = (fn1 is not None and fn1 is fn2 and state is not None and getattr(fn1, "takes_head_gscale", False)
+                          and getattr(fn1, "state", None) is state)
                 loss, y = MLPLossFn.apply(tape, x, x2, t, G, state, direct, *wb)
             else:
                 loss, y = MLPLossFn.apply(None, x, x2, t, None, None, False, *[l.W for l in ls], *[l.b for l in ls])

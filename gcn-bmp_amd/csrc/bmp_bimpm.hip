@@ -465,12 +465,7 @@ extern "C" int bmp_bimpm_fwd(const float* X1, const float* X2, int d, int H, con
     if (rc) return rc;
     BMP_REQUIRE(out1 && out2 && ws_floats >= bmp_bimpm_ws_floats(d, H, maxn, B, 0));
     a.out1 = out1; a.out2 = out2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_bimpm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_bimpm<false>, (size_t)(160 * 1024))) return rc_attr;
     hipLaunchKernelGGL((k_bimpm<false>), dim3(bm_grid(B)), dim3(BM_NT), bm_lds_bytes(maxn, d), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
@@ -489,12 +484,7 @@ extern "C" int bmp_bimpm_bwd(const float* dout1, const float* dout2, const float
     a.dout1 = dout1; a.dout2 = dout2; a.dX1 = dX1; a.dX2 = dX2;
     const int grid = bm_grid(B);
     a.wslab = ws + (size_t)grid * a.scratch_per_wg;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_bimpm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_bimpm<true>, (size_t)(160 * 1024))) return rc_attr;
     hipLaunchKernelGGL((k_bimpm<true>), dim3(grid), dim3(BM_NT), bm_lds_bytes(maxn, d), st, a);
     BMP_LAUNCH_CHECK();
     const int n = 3 * H * d;

@@ -800,19 +800,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-static int co_set_lds(const void* fn, size_t bytes) {
-    static const void* done[16] = {nullptr};       // the kernel instances in use: set once each, not per launch
-    for (int i = 0; i < 16; ++i) {
-        if (done[i] == fn) return 0;
-        if (done[i] == nullptr) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            if (e != hipSuccess) return (int)e;
-            done[i] = fn;
-            return 0;
-        }
-    }
-    return -1;
-}
+static int co_set_lds(const void* fn, size_t bytes) { return bmp_lds_attr(fn, bytes); }      // once per (kernel, device)
 
 // ZC = o + H + 1 rounded up to a multiple of 8: J (o) | P (H) | v | pad
 extern "C" int bmp_coattn_zcols(int o, int H) { return (o + H + 1 + 7) & ~7; }

@@ -20,6 +20,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (e__ != hipSuccess) return (int)e__;                   \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set once per (kernel, device), not per
+// launch and not once per process (a host that drives two devices from one process would find the second one unset).
+// Lock-free table, safe from several host threads (setting an attribute twice is harmless).
+#include <atomic>
+struct BmpAttrSlot { std::atomic<const void*> fn{nullptr}; std::atomic<unsigned long long> devs{0}; };
+inline int bmp_lds_attr(const void* fn, size_t bytes) {
+    static BmpAttrSlot tab[96];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    for (int i = 0; i < 96; ++i) {
+        const void* cur = tab[i].fn.load(std::memory_order_acquire);
+        if (cur == nullptr) {
+            const void* expect = nullptr;
+            cur = tab[i].fn.compare_exchange_strong(expect, fn, std::memory_order_acq_rel) ? fn : expect;
+        }
+        if (cur != fn) continue;
+        if (tab[i].devs.load(std::memory_order_acquire) & bit) return 0;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        tab[i].devs.fetch_or(bit, std::memory_order_release);
+        return 0;
+    }
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);      // table full: per launch
+}
+
 #define BMP_REQUIRE(cond)                                         \
     do {                                                          \
         if (!(cond)) return -1000 - __LINE__;                     \

@@ -961,12 +961,7 @@ static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, double rows, hip
                    : kind == 1 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false, false>
                    : kind == 3 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true, true>
                                : (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false, true>;
-    static bool attr_set[5] = {false, false, false, false, false};      // per template instance, per kind: set once, not per launch
-    if (!attr_set[kind]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
-        if (e != hipSuccess) return (int)e;
-        attr_set[kind] = true;
-    }
+    if (int rc_attr = bmp_lds_attr(fn, (size_t)((int)fz_lds_bytes(D)))) return rc_attr;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
     // (all T steps in one launch: the first step's work + T - 1 later steps')
     const double macs = ts ? (4.0 + gates) + (a.T - 1) * 11.0 : (4.0 + gates);
@@ -1121,12 +1116,7 @@ extern "C" int bmp_relgcn_layer_supported(int d_in, int d_out) { return d_in == 
 template <int D, bool VAR>
 static int rel_launch2(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
     const void* fn = bwd ? (const void*)k_relgcn_layer_bwd<D, VAR> : (const void*)k_relgcn_layer_fwd<D, VAR>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[bwd ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fz_lds_bytes(D));
-        if (e != hipSuccess) return (int)e;
-        attr_set[bwd ? 1 : 0] = true;
-    }
+    if (int rc_attr = bmp_lds_attr(fn, (size_t)((int)fz_lds_bytes(D)))) return rc_attr;
     const double rows = VAR ? (double)a.mt_rows : (double)n_tiles * FZ_R;
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * 5.0 * D * D, 4.0 * rows * D * (bwd ? 8.0 : 2.0), st,
                       BMP_KID_RELGCN);
@@ -1211,13 +1201,7 @@ static size_t ro_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + 400 + F
 
 template <int D, bool HAS0>
 static int ro_launch(const ROArgs& a, int n_tiles, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_readout_tile_fwd<D, HAS0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)ro_lds_bytes(D));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_readout_tile_fwd<D, HAS0>, (size_t)((int)ro_lds_bytes(D)))) return rc_attr;
     const double rows = (double)n_tiles * FZ_R;
     BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * (HAS0 ? 2.0 : 1.0) * D * 2.0 * D, 4.0 * rows * D * (HAS0 ? 4.0 : 3.0), st,
                       BMP_KID_READOUT_TILE);

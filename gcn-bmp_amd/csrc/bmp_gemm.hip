@@ -1014,13 +1014,7 @@ static int wgrad_multi_launch(WGKMulti& m, int n, const dim3& grid, hipStream_t 
     }
     m.ssz = WD_RS * 128 * (x2 ? 3 : 2) + WD_RS * 4;          // + the rows' four weights
     const size_t lds = (size_t)WD_NS * m.ssz * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_dma_multi<STEP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           WD_NS * (WD_RS * 128 * 3 + WD_RS * 4) * (int)sizeof(float));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_wgrad_dma_multi<STEP>, (size_t)(WD_NS * (WD_RS * 128 * 3 + WD_RS * 4) * (int)sizeof(float)))) return rc_attr;
     hipLaunchKernelGGL((k_wgrad_dma_multi<STEP>), grid, dim3(256), lds, st, m);
     return 0;
 }

@@ -192,12 +192,7 @@ extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, in
     }
     const size_t lds_bytes = ((size_t)V * d + V) * sizeof(float);
     BMP_REQUIRE(lds_bytes <= 160 * 1024);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_embed_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_embed_bwd, (size_t)(160 * 1024))) return rc_attr;
     const int nb = (N + EMB_ROWS_PER_BLOCK - 1) / EMB_ROWS_PER_BLOCK;
     float* slab = ws;
     int* flags = (int*)(ws + (size_t)nb * V * d);

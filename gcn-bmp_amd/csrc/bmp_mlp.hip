@@ -218,12 +218,7 @@ extern "C" int bmp_mlp_fwd(const float* x1, int d1, const float* x2, int d2, int
     int rc = mlp_fill(a, x1, d1, x2, d2, B, nl, dims, W, b, act);
     if (rc) return rc;
     const size_t wt_bytes = (size_t)dims[0] * (dims[1] + 1) * sizeof(float);          // <= 1024 x 65 floats
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 65536);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_mlp_fwd, (size_t)(160 * 1024 - 65536))) return rc_attr;
     BMP_REQUIRE(wt_bytes + 65536 <= 160 * 1024);
     hipLaunchKernelGGL(k_mlp_fwd, dim3((B + MLP_FR - 1) / MLP_FR), dim3(256), wt_bytes, st, a);
     BMP_LAUNCH_CHECK();
@@ -449,12 +444,7 @@ extern "C" int bmp_mlp_sce_fwdbwd(const float* x1, int d1, const float* x2, int 
     HeadArgs h{t, dy, part, ticket, loss, sums};
     size_t wt_bytes = (size_t)dims[0] * (dims[1] + 1) * sizeof(float);
     for (int l = 1; l < nl; ++l) wt_bytes += (size_t)dims[l + 1] * (dims[l] + 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_sce, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 49152);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_attr = bmp_lds_attr((const void*)k_mlp_sce, (size_t)(160 * 1024 - 49152))) return rc_attr;
     BMP_REQUIRE(wt_bytes + 49152 <= 160 * 1024);
     hipLaunchKernelGGL(k_mlp_sce, dim3((B + MLP_BR - 1) / MLP_BR), dim3(256), wt_bytes, st, a, h);
     BMP_LAUNCH_CHECK();

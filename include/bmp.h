@@ -8,8 +8,13 @@
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc / torch caching allocator), 16-byte aligned;
  *     float = IEEE fp32, int = int32.  The library never allocates, frees, retains a pointer
- *     past the call, synchronises the host or keeps global state: a call only enqueues kernels
- *     on `stream`.
+ *     past the call, synchronises the host or keeps result-bearing global state: a call only
+ *     enqueues kernels on `stream`.  What the library does remember, process-wide: (i) which
+ *     (kernel, device) pairs already had hipFuncAttributeMaxDynamicSharedMemorySize raised
+ *     (lock-free, per device: one process may drive several devices, from several host threads);
+ *     (ii) A/B switches read once from the environment (BMP_WGRAD_DMA, BMP_WGRAD_XCD,
+ *     BMP_STEP_WGRAD_UNFUSED, BMP_ROWGEMM_FORM / _DIRECT: diagnostics of tools/ and tests/);
+ *     (iii) the opt-in event timer bmp_prof_*.  None of them changes a result.
  *   - row-indexed arrays use the packed layout of bmp/packed.py: N = n_tiles * bmp_tile_rows()
  *     rows (128 per tile, molecules never straddle a tile, dead rows are zero-weight).
  *   - weights come in two layouts: "T" = K-major [in x out] (used as the GEMM B operand) and

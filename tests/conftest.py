@@ -18,16 +18,21 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-def pytest_sessionstart(session):
-    # achieved-error log of tests/parity_util.py: one file per session
-    log = os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl")
-    try:
-        os.remove(log)
-    except OSError:
-        pass
+def pytest_collection_finish(session):
+    # achieved-error log of tests/parity_util.py: a fresh file for every session that RUNS gpu-marked tests; a CPU-only
+    # session (-m "not gpu") logs nothing and must leave the last GPU session's log and summary alone
+    session.config._bmp_gpu_session = any(it.get_closest_marker("gpu") is not None for it in session.items)
+    if session.config._bmp_gpu_session:
+        for name in ("parity_errors.jsonl", "parity_summary.json"):
+            try:
+                os.remove(os.path.join(ROOT, "gpurun_out", name))
+            except OSError:
+                pass
 
 
 def pytest_sessionfinish(session, exitstatus):
+    if not getattr(session.config, "_bmp_gpu_session", False):
+        return
     try:
         import parity_util
         parity_util.summarize()

@@ -51,8 +51,13 @@ def _dense(store, idx, A):
     return T(atoms), T(adj)
 
 
-def _run(config):
-    from bmp import packed, synth
+def _run(config, mode="loss"):
+    """mode "loss": the step exactly as bench.py's Env.train_step takes it -- ``opt.functional_loss(pb, t=t)``: the one-launch
+    head k_mlp_sce, the loss-gradient factor handed to the pair kernels as a device scalar, the deferred weight-gradient
+    launches, all streams on.  "forward+loss": ``functional_forward`` + ``model.loss`` (the separate launches; the control).
+    "dedup": the bench's de-duplication leg -- ``enclayout.encode_from_store_device(..., dedup=True)`` through
+    ``functional_loss`` -- against the ORACLE (not against the per-instance step)."""
+    from bmp import enclayout, packed, synth
     from bmp.dp import FlatAdam
     from bmp.predictor import build_pair_predictor
     from bmp.snapshot import load_param_dict
@@ -102,34 +107,63 @@ def _run(config):
     load_param_dict(model, p)
     opt = FlatAdam(model, alpha=1e-3)
     ds = packed.DeviceMolStore(ms, dev)
-    pb, t = packed.pack_from_store_device(ds, [i1, i2], labels=masked)
+    if mode == "dedup":
+        pb, t = enclayout.encode_from_store_device(ds, [i1, i2], labels=masked, dedup=True)
+        assert pb.n_encoded < 600 and pb.pb_enc.n_rows < pb.pb.n_rows / 3          # ~530 distinct molecules of 2048 instances
+    else:
+        pb, t = packed.pack_from_store_device(ds, [i1, i2], labels=masked)
+    tag = f"{config}/{mode}"
     for rep in range(2):                                    # twice: nothing stale may survive from the step before
-        y = opt.functional_forward(pb)
+        if mode == "forward+loss":
+            y = opt.functional_forward(pb)
+            loss = model.loss(y, t)
+        else:
+            loss = opt.functional_loss(pb, t=t)             # bench.py Env.train_step
+            y = model.y
         assert opt.plan is not None and "graph_conv." in opt.plan.P
         assert opt.plan.side is not None and opt.plan.split is not None, "the timed configuration runs with its streams on"
-        loss = model.loss(y, t)
         loss.backward()
         opt.collect_grads()
         torch.cuda.synchronize()
-        close(y[T(pick).to(dev)], yo, f"{config} logits of the live pairs (rep {rep})", tol=TOL)
-        close(loss, lo, f"{config} loss (rep {rep})", tol=TOL)
+        close(y[T(pick).to(dev)], yo, f"{tag} logits of the live pairs (rep {rep})", tol=TOL)
+        close(loss, lo, f"{tag} loss (rep {rep})", tol=TOL)
         off, worst = 0, 0.0
         for name, shp in zip(opt.names, opt.shapes):
             n = int(np.prod(shp))
-            worst = max(worst, close(opt.grad[off:off + n].view(shp), go[name.replace(".", "/")], f"{config} grad {name} (rep {rep})",
+            worst = max(worst, close(opt.grad[off:off + n].view(shp), go[name.replace(".", "/")], f"{tag} grad {name} (rep {rep})",
                                      tol=TOL))
             off += n
-    assert pb.n_tiles > 256 and len(pick) >= 8
+        assert opt.plan.state.get("head_gscale") is None, "the loss-gradient factor was handed over and consumed"
+    assert getattr(pb, "pb", pb).n_tiles > 256 and len(pick) >= 8
     return worst
 
 
-def test_c2_full_size_backward_matches_oracle_on_live_pairs():
-    _run("c2")
+# ---- the step as bench.py times it: opt.functional_loss (one-launch head + gscale into the pair kernels) ----
+def test_c2_timed_step_matches_oracle_on_live_pairs():
+    _run("c2", "loss")
 
 
-def test_c3_full_size_backward_matches_oracle_on_live_pairs():
-    _run("c3")
+def test_c3_timed_step_matches_oracle_on_live_pairs():
+    _run("c3", "loss")
 
 
-def test_c4_full_size_backward_matches_oracle_on_live_pairs():
-    _run("c4")
+def test_c4_timed_step_matches_oracle_on_live_pairs():
+    _run("c4", "loss")
+
+
+# ---- control: the separate launches (functional_forward + model.loss), round 3's form of this test ----
+def test_c2_forward_plus_loss_matches_oracle_on_live_pairs():
+    _run("c2", "forward+loss")
+
+
+def test_c3_forward_plus_loss_matches_oracle_on_live_pairs():
+    _run("c3", "forward+loss")
+
+
+# ---- the bench's `dedup` leg (every distinct molecule encoded once) against the oracle at 1024 pairs ----
+def test_c2_dedup_step_matches_oracle_on_live_pairs():
+    _run("c2", "dedup")
+
+
+def test_c3_dedup_step_matches_oracle_on_live_pairs():
+    _run("c3", "dedup")
