@@ -19,6 +19,9 @@ Rank 0 prints ONE JSON line:
   predict       forward only, under no-backprop: the evaluation callers' predict (eval_coattention.py:103-124)
   dedup         every distinct molecule of a step encoded once (SURVEY.md 8(d) caveat): reported beside `value`, never instead
   other_configs the default (c2) run also times c3 and c4 for 20 steps each, with their dominant kernel's roofline fraction
+  ref_headline  the model the reference's published figures were trained with (DDI.md:6, RECORD.txt:246-251): GGNN hidden 32, 8
+                steps untied + Nie + NTN / HolE, at 1024 pairs (resident) and at the reference's batch of 32; fused d = 32 step
+                kernels against the unfused operator chain
   roofline      the dominant kernel and its class: durations from HIP events around every launch, measured in this run;
                 `traffic` (HBM bytes per launch) is NOT measured in this run -- PMC counters need rocprofv3 -- but quoted from
                 the committed profile named in `traffic_source` (same library version, config and kernel), null without one
@@ -83,6 +86,13 @@ CONFIGS = {
     "c3": dict(encoder="relgcn", d=128, o=128, layers=3, attn="nie", class_num=1, store="binary",
                workload="C3: full binary DDI set, RelGCN 3-layer d=128 (scale_adj) + atoms tap + Nie co-attention + MLP(32,16), "
                         "fwd+bwd+Adam"),
+    # the model every published figure of the reference was trained with (DDI.md:6, RECORD.txt:246-251): not a BASELINE.json
+    # config -- the `ref_headline` leg of the default run
+    "ref_ntn": dict(encoder="ggnn", d=32, o=16, layers=8, attn="nie", class_num=1, store="binary", tying=False, sim="ntn", mlp_hidden=(),
+                    workload="reference's published model: GGNN hidden 32, 8 steps, weight_tying=False, fp_out 16 + Nie(head 8) + NTN "
+                             "(--net-hidden-dims=), binary DDI set, fwd+bwd+Adam"),
+    "ref_hole": dict(encoder="ggnn", d=32, o=16, layers=8, attn="nie", class_num=1, store="binary", tying=False, sim="hole", mlp_hidden=(),
+                     workload="as ref_ntn with the HolE link predictor (DDI.md:6)"),
     "c4": dict(encoder="ggnn", d=256, o=256, layers=4, attn=None, class_num=37, store="multilabel",
                workload="C4: 37-class multi-label DDI (1704 drugs, 192000 pairs), GGNN 4-step d=256 tied + MLP(32,16) -> 37, "
                         "fwd+bwd+Adam"),
@@ -119,6 +129,10 @@ def algorithmic_flops_per_pair(cfg, n_pair: float):
     else:
         enc, readout = 10.0 * d * d * n_pair * L, 4.0 * d * o * n_pair
     mlp = 2.0 * (2 * o * 32 + 32 * 16 + 16 * cfg["class_num"])
+    if cfg.get("sim") == "ntn":          # Bilinear(o, o, 8) + V1, V2 (models/mlp.py:52) and the 8 -> class_num output layer
+        mlp = 2.0 * (8 * o * o + 2 * 8 * o + 8 * cfg["class_num"])
+    elif cfg.get("sim") == "hole":       # circular correlation as the direct sum (o^2 multiply-adds) + o -> class_num
+        mlp = 2.0 * (o * o + o * cfg["class_num"])
     if cfg["attn"]:
         co = 2.0 * (half * d * d + half * half * d + n_pair * d * o + 2 * n_pair * HEAD * d)
         return 3.0 * (enc + co + mlp) + readout
@@ -239,7 +253,7 @@ def main():
     # 32-pair batch gains 14 % (its tiles spread over four times as many CUs).  So: per-instance batches for the 1024-pair
     # legs, the encoder layout for the 32-pair leg and -- always -- for de-duplication.
     LAYOUT = os.environ.get("BMP_BENCH_LAYOUT", "auto")
-    AUTO = {"c2": "instance", "c3": "instance", "c4": "instance"}
+    AUTO = {"c2": "instance", "c3": "instance", "c4": "instance", "ref_ntn": "instance", "ref_hole": "instance"}
     from bmp.dp import FlatAdam
     L = _lib.lib()
 
@@ -294,7 +308,8 @@ def main():
             self.edges_per_pair = sum(pb.n_edges for pb in inst) / (len(self.batches) * PAIRS_PER_GPU)
             torch.manual_seed(777)
             self.model = build_pair_predictor(hidden_dim=c["d"], out_dim=c["o"], n_layers=c["layers"], attn=c["attn"], head=HEAD,
-                                              encoder=c["encoder"], class_num=c["class_num"]).to(dev)
+                                              encoder=c["encoder"], class_num=c["class_num"], weight_tying=c.get("tying", True),
+                                              sim_method=c.get("sim", "mlp"), mlp_hidden=c.get("mlp_hidden", (32, 16))).to(dev)
             self.opt = FlatAdam(self.model, alpha=1e-3)
             self.opt.broadcast_parameters(0)
             if force_pg:
@@ -311,7 +326,7 @@ def main():
             # (the encoder layout pays through the fused tile kernels, d = 64 / 128; the row-wise operators of other widths
             #  gain nothing from tile heights and would only carry the two extra index launches)
             layout = layout or (AUTO[self.name] if LAYOUT == "auto" else LAYOUT)
-            if (layout == "instance" or self.cfg["d"] not in (64, 128)) and not dedup:
+            if (layout == "instance" or self.cfg["d"] not in (32, 64, 128)) and not dedup:
                 return packed.pack_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B])
             return enclayout.encode_from_store_device(self.dstore, [i1[lo:lo + B], i2[lo:lo + B]], labels=lab[lo:lo + B], dedup=dedup)
 
@@ -542,13 +557,56 @@ def main():
                                 per_kernel_ms_per_step=None if r is None else r["per_kernel_ms_per_step"])
             env = e
 
+    # ---- the reference's PUBLISHED model (DDI.md:6, RECORD.txt:246-251; train_binary.py:165-187,226-227): GGNN hidden 32, 8
+    #      steps, untied, fp_out 16 + Nie + NTN / HolE without hidden layers, at the reference's batch of 32 and at 1024 pairs ----
+    ref_head = None
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "c2" and os.environ.get("BMP_BENCH_REF", "1") != "0":
+        ref_head = {}
+        for name in ("ref_ntn", "ref_hole"):
+            torch.cuda.empty_cache()
+            e = Env(name, n_batches=24)
+            v, dt_r, _, loss_r = e.resident(30, 6)
+            ent = dict(batch1024=dict(value=round(v, 1), unit="pairs/s", ms_per_step=round(1e3 * dt_r / 30, 3), steps=30,
+                                      f32_frac=e.whole(v)["f32_frac"], alg_mflop_per_pair=e.whole(v)["alg_mflop_per_pair"],
+                                      loss=round(loss_r, 5)), workload=e.cfg["workload"])
+            if name == "ref_ntn":
+                # the same model with its propagation steps on the unfused operators (gather + message row GEMM + the GRU's
+                # row GEMMs: what d = 32 ran before the one-wave-per-block kernels of csrc/bmp_fused_small.hip): A/B, same box
+                e.model.graph_conv.fused_small = False
+                e.opt = FlatAdam(e.model, alpha=1e-3)
+                v_u, dt_u, _, _ = e.resident(30, 6)
+                ent["batch1024"]["unfused_value"] = round(v_u, 1)
+                ent["batch1024"]["fused_speedup"] = round(v / v_u, 3)
+                e.model.graph_conv.fused_small = True
+                e.opt = FlatAdam(e.model, alpha=1e-3)
+            # batch 32, end to end (collate inside), the reference's default (train_binary.py:330)
+            for lay in ("instance", "encoder"):
+                b32s = [e.collate(e.idx1, e.idx2, e.label, k, B=32, layout=lay) for k in range(64)]
+                for i in range(10):
+                    e.train_step(*b32s[i])
+                n_b = 200
+                t_host = [0.0]
+                def body32(i):
+                    t0 = time.perf_counter()
+                    e.train_step(*b32s[i % 64])
+                    t_host[0] += time.perf_counter() - t0
+                dt_b, _ = timed(n_b, body32)
+                ent[f"batch32_{lay}"] = dict(value=round(32 * n_b / dt_b, 1), unit="pairs/s", ms_per_step=round(1e3 * dt_b / n_b, 3),
+                                             host_ms_per_step=round(1e3 * t_host[0] / n_b, 3), steps=n_b,
+                                             f32_frac=round(32 * n_b / dt_b * e.alg_f / (PEAK_F32_TFLOPS * 1e12), 5))
+                del b32s
+            ref_head[name] = ent
+            del e
+
     cpu = cpu_more = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, cpu_more = cpu_baseline(cfg, store, idx1, idx2, label)
 
     if rank == 0:
         names = {"c2": "drug-pairs/sec fwd+bwd, binary-DDI GGNN d=128", "c3": "drug-pairs/sec fwd+bwd, binary-DDI RelGCN d=128",
-                 "c4": "drug-pairs/sec fwd+bwd, 37-class multi-label DDI GGNN d=256"}
+                 "c4": "drug-pairs/sec fwd+bwd, 37-class multi-label DDI GGNN d=256",
+                 "ref_ntn": "drug-pairs/sec fwd+bwd, binary-DDI GGNN d=32 x 8 untied + Nie + NTN",
+                 "ref_hole": "drug-pairs/sec fwd+bwd, binary-DDI GGNN d=32 x 8 untied + Nie + HolE"}
         line = {
             "metric": names[args.config], "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -562,7 +620,7 @@ def main():
                        "atoms_per_pair": round(atoms_per_pair_main, 2), "real_row_fraction": round(real_row_fraction_main, 4),
                        "loss": round(loss_val, 5)},
             "roofline": roof, "whole_step": whole, "end_to_end": e2e, "batch32": b32, "predict": pred, "dedup": dedup, "other_configs": others,
-            "cpu_baseline": cpu}
+            "ref_headline": ref_head, "cpu_baseline": cpu}
         if cpu_more:
             line["cpu_baseline_more"] = cpu_more
         if rank_ms:

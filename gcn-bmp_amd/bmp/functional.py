@@ -653,7 +653,7 @@ _TSTEPS = os.environ.get("BMP_TSTEPS", "0") == "1"
 
 
 def tsteps_supported(d: int, T: int) -> bool:
-    return _TSTEPS and step_supported(d) and 1 <= T <= 8
+    return _TSTEPS and d in (64, 128) and step_supported(d) and 1 <= T <= 8
 
 
 class PTStepsFn(Function):

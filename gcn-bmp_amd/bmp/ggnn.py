@@ -279,9 +279,13 @@ class GGNN(nn.Module):
     def plannable(self) -> bool:
         return self.fused and not self.concat_hidden and self.dropout_rate == 0.0
 
+    # d = 32 (the reference's published width) has fused step kernels of its own (csrc/bmp_fused_small.hip); ``fused_small =
+    # False`` sends that width through the unfused operators again (bench.py's A/B of the two, tests)
+    fused_small = True
+
     def _plan_fused(self) -> bool:
-        """The plan's arrays are those of the fused step kernels (d = 64 / 128) or of the unfused operators (other widths)."""
-        return Fn.step_supported(self.hidden_dim)
+        """The plan's arrays are those of the fused step kernels (d = 32 / 64 / 128) or of the unfused operators (other widths)."""
+        return Fn.step_supported(self.hidden_dim) and (self.hidden_dim >= 64 or self.fused_small)
 
     def _step_groups(self):
         """(message layer, GRU mode) of every step, in step order (models/ggnn.py:220, first call after reset)."""
@@ -431,7 +435,7 @@ class GGNN(nn.Module):
         pb.check_atom_ids(self.embed.W.shape[0])
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id)
         h0 = h
-        fused = self.fused and Fn.step_supported(self.hidden_dim) and not pb.oversized
+        fused = self.fused and self._plan_fused() and not pb.oversized
         later, msgw, cache = None, {}, {}
         for step in range(self.n_layers):
             li = 0 if self.weight_tying else step
@@ -484,7 +488,7 @@ class GGNN(nn.Module):
         h = Fn.EmbedFn.apply(self.embed.W, pb.atom_id) if h_in is None else h_in      # :603
         h0 = h                                                          # :612
         later = None
-        fused = self.fused and Fn.step_supported(self.hidden_dim) and not drop and not big
+        fused = self.fused and self._plan_fused() and not drop and not big
         state, state_w = None, None           # dropout: the GRU's own (un-dropped) state and its unfolded weights
         masks = getattr(self, "_dropout_masks", None)      # tests inject the masks (one (n_rows, d) tensor per step)
         g_list = []

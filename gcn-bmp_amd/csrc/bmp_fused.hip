@@ -16,272 +16,7 @@
 #include <string.h>
 #include "bmp_kernels.h"
 
-#define FZ_R 128
-#define FZ_TMAX 8         // propagation steps of one multi-step forward launch
-
-struct StepArgs {
-    // graph
-    const int* ptr; const int* col; const float* val;      // CSR (fwd) or transposed CSR (bwd)
-    int tile0;                      // the launch covers tiles tile0 .. tile0 + gridDim.x - 1 (all arrays whole)
-    int first;
-    // optional tile table (nullptr: tile t = rows [128 t, 128 t + 128)): tile t = rows [mt_row0[t], + 32 * mt_nblk[t]),
-    // mt_nblk in 1..4 -- tiles of fewer live 32-row blocks skip the dead blocks' gathers, MFMAs, loads and stores
-    const int* mt_row0; const int* mt_nblk;
-    int mt_rows;                    // rows of the launch's tiles when a table is given (host-side accounting only)
-    // forward
-    const float* h;                 // [N x D] step input
-    const float* WT;                // [4D x D]  message weights, K-major (row e*D + k, col c)
-    const float* bE;                // [4 x D]
-    const float* AT;                // [2D x 3D] gate weights K-major, rows [h ; m], cols [r | z | c]
-    const float* UcT;               // [D x D]
-    const float* b;                 // [3D]
-    float* m; float* rz; float* c; float* hout;
-    // backward
-    const float* dhout;             // [N x D]
-    const float* Wnat;              // [D x 4D]  (= WT^T: row c, col e*D + k)
-    const float* A;                 // [3D x 2D] (= AT^T)
-    const float* Uc;                // [D x D]   (= UcT^T, reference layout)
-    float* dh;                      // [N x D]
-    float* gda;                     // [N x 7D]: G (4D: gathered dm per bond type) | da_r | da_z | da_c
-    // all T steps of a tile in one forward launch (k_ggnn_step_fwd<.., TS = true>): step t's weights and outputs
-    int T;
-    const float* ts_WT[FZ_TMAX]; const float* ts_bE[FZ_TMAX]; const float* ts_AT[FZ_TMAX]; const float* ts_b[FZ_TMAX];
-    float* ts_m[FZ_TMAX]; float* ts_rz[FZ_TMAX]; float* ts_c[FZ_TMAX]; float* ts_hout[FZ_TMAX];
-};
-
-// acc[nb][rb] += A(rows of this wave, K) . B_nb(K, 32 cols)   with A in LDS, B streamed from global.
-//   As_wave = &tile[(wave_row0 + (lane & 31)) * LD + 4 * (lane >> 5)]
-//   Bp[nb]  = B_nb + 4 * (lane >> 5) * ldw[nb] + col      (col = this lane's output column)
-// `rot` (multiple of 8, < K) rotates the K loop: workgroups walk the shared weight matrices from different
-// starting rows, so the 256 CUs do not all request the same L2 lines at the same moment.
-// The first two B fragments of a tile_mma call, requested early: every call otherwise opens with an L2 round trip
-// during which the matrix pipe has nothing to do (7-8 calls per tile).  The caller issues the prefetch before the
-// gather / epilogue / group barrier that precedes the call.
-template <int NB>
-struct BPre { f32x4 b0[NB], b1[NB]; };
-template <int NB>
-__device__ __forceinline__ void tile_b_prefetch(BPre<NB>& p, const float* const (&Bp)[NB], const int (&ldw)[NB], int K, int rot) {
-    int k1 = rot + 8; if (k1 >= K) k1 -= K;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        p.b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)rot * ldw[nb]);
-        p.b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
-    }
-}
-
-// NRB (<= RB): live row blocks of this wave (a short tile of the encoder layout); the other blocks' A loads and MFMAs do not
-// exist in that instance.
-template <int NB, int RB, int NRB = RB>
-__device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
-    // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
-    // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
-    // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
-    f32x4 b0[NB], b1[NB], b2[NB];
-    int k = rot;
-    int k1 = k + 8; if (k1 >= K) k1 -= K;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        if (pre) { b0[nb] = pre->b0[nb]; b1[nb] = pre->b1[nb]; }
-        else {
-            b0[nb] = *(const f32x4*)(Bp[nb] + (size_t)k * ldw[nb]);
-            b1[nb] = *(const f32x4*)(Bp[nb] + (size_t)k1 * ldw[nb]);
-        }
-    }
-    f32x4 a0[NRB], a1[NRB];          // A fragments (LDS) run one k-step ahead
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) a0[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
-    for (int it = 0; it < K; it += 8) {
-        int k2 = k1 + 8; if (k2 >= K) k2 -= K;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) b2[nb] = *(const f32x4*)(Bp[nb] + (size_t)k2 * ldw[nb]);
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) a1[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = bmp_mfma(a0[rb][t], b0[nb][t], acc[nb][rb]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { b0[nb] = b1[nb]; b1[nb] = b2[nb]; }
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) a0[rb] = a1[rb];
-        k = k1; k1 = k2;
-    }
-}
-
-// tile_mma for a wave with `nrb` live row blocks (0: nothing to do).  VAR == false: whole tiles, nrb == RB at compile time.
-template <bool VAR, int NB, int RB>
-__device__ __forceinline__ void tile_mma_n(int nrb, f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                           const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
-    if constexpr (!VAR) {
-        tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
-    } else if constexpr (RB == 1) {
-        if (nrb > 0) tile_mma<NB, 1, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
-    } else {
-        if (nrb == RB) tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
-        else if (nrb > 0) tile_mma<NB, RB, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-}
-
-// Tile-local neighbour gather for one bond type: dst[row, :] = sum over CSR entries of `row` with type e of
-// val * src_tile[col_local, :].  4 threads per row, D/4 columns each.  Returns (per thread) whether it saw a
-// matching entry; *wsum gets the row's weighted degree for that type.
-// ptr is indexed by the tile-local row; col/val by the entry index ptr yields (either the kernel's global CSR
-// arrays, or the copy of the tile's entries staged in LDS -- see stage_csr).
-template <int D>
-__device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_tile, int LD, const int* ptr, const int* col,
-                                            const float* val, int row0, int e, float* wsum, int* tmask, int nrows = FZ_R) {
-    constexpr int F = D / 16;                 // float4 per thread
-    const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
-    f32x4 acc[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float wd = 0.f;
-    bool any = false;
-    *wsum = 0.f;
-    if (nrows < FZ_R && row >= nrows) return false;       // a dead block of a short tile: nothing reads its rows
-    const int e0 = ptr[row], e1 = ptr[row + 1];
-    for (int ed = e0; ed < e1; ++ed) {
-        const int cv = col[ed];
-        *tmask |= 1 << (cv & 3);
-        if ((cv & 3) == e) {
-            const float v = val[ed];
-            const float* s = src_tile + ((cv >> 2) - row0) * LD + q * (D / 4);
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f] += *(const f32x4*)(s + 4 * f) * v;
-            wd += v;
-            any = true;
-        }
-    }
-    float* o = dst_tile + row * LD + q * (D / 4);
-#pragma unroll
-    for (int f = 0; f < F; ++f) *(f32x4*)(o + 4 * f) = acc[f];
-    *wsum = wd;
-    return any;
-}
-
-// The tile's CSR entries -> LDS (the gather loops are chains of dependent loads: from L2 they cost several
-// microseconds per bond-type pass).  Returns false (and stages nothing) if the tile has more than FZ_ECAP entries.
-#define FZ_ECAP 1024
-__device__ __forceinline__ bool stage_csr(const int* ptr, const int* col, const float* val, int row0, int* rptr, int* ecol,
-                                          float* evalv, int nrows = FZ_R) {
-    const int ebase = ptr[row0];
-    const int ne = ptr[row0 + nrows] - ebase;
-    if (ne > FZ_ECAP) return false;
-    for (int i = threadIdx.x; i <= nrows; i += 512) rptr[i] = ptr[row0 + i] - ebase;
-    for (int i = threadIdx.x; i < ne; i += 512) { ecol[i] = col[ebase + i]; evalv[i] = val[ebase + i]; }
-    return true;
-}
-#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp, &tmask, nrows) \
-                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp, &tmask, nrows))
-
-// ---- half-tile groups --------------------------------------------------------------------------------------
-// Waves 0-3 own rows [0, 64) of the tile and waves 4-7 rows [64, 128) in every phase (gather rows, MFMA A rows,
-// epilogue rows), so between the few points where a phase reads the WHOLE tile the two halves are independent.
-// They synchronise separately, on a monotonic LDS counter per group (gfx950 has one hardware barrier per
-// workgroup), and group 0 runs at a higher wave priority: with one wave of each group on every SIMD, group 0
-// takes the matrix pipe whenever it wants it and group 1 fills the gaps group 0 leaves while it gathers, runs
-// epilogues or waits for memory.  In lockstep (one barrier for all eight waves) both waves of a SIMD sit in their
-// non-MFMA phases at the same time and the matrix pipe idles for a third of the tile's life.
-struct GrpSync {
-    int* ctr;       // LDS, zeroed before the first workgroup barrier
-    int target;
-};
-__device__ __forceinline__ void grp_sync(GrpSync& g) {
-    g.target += 4;                                   // four waves per group
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(g.ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(g.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g.target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-#define FZ_NSYNC 8          // ints of LDS: ctr[2] at +0,+1 ; type masks [2] at +2,+3
-
-// Accumulator-layout access to a row-major [rows x LDC] f32 array through a buffer resource: all 16*RB
-// positions of a wave share ONE 32-bit voffset VGPR (the lane's (row, col) byte offset); the per-register
-// row offset is a compile-time soffset/immediate.  (Plain pointers cost a 64-bit address pair per element
-// here, which the register allocator keeps alive across the MFMA phases and spills.)
-struct AccBuf {
-    __amdgpu_buffer_rsrc_t rs;
-    int vo;
-};
-template <int LDC>
-__device__ __forceinline__ AccBuf acc_buf(const float* base, int tile_row0, int lane_row, int col) {
-    AccBuf b;
-    b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)tile_row0 * LDC), 0, 0x7FFFFFFF, 0x00020000);
-    b.vo = (lane_row * LDC + col) * 4;
-    return b;
-}
-template <int LDC>
-__device__ __forceinline__ float acc_ld(const AccBuf& b, int rb, int reg, int coff = 0) {
-    const int so = ((rb * 32 + (reg & 3) + 8 * (reg >> 2)) * LDC + coff) * 4;
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rs, b.vo, so, 0));
-}
-template <int LDC>
-__device__ __forceinline__ void acc_st(const AccBuf& b, int rb, int reg, float v, int coff = 0) {
-    const int so = ((rb * 32 + (reg & 3) + 8 * (reg >> 2)) * LDC + coff) * 4;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.rs, b.vo, so, 0);
-}
-
-// Row-major access to one 64-row half of a tile, 16 bytes per lane: slot v of thread tg (0..255) is the
-// float4 at (half row v * (1024 / D) + tg / (D/4), float4 column tg % (D/4)); the per-slot row offset is a
-// compile-time soffset, so all slots of one array share one voffset VGPR (see AccBuf).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int D, int LDP>
-__device__ __forceinline__ AccBuf rm_buf(const float* base, int tile_row0, int grp, int tg) {
-    AccBuf b;
-    b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)tile_row0 * LDP), 0, 0x7FFFFFFF, 0x00020000);
-    b.vo = ((grp * 64 + tg / (D / 4)) * LDP + 4 * (tg % (D / 4))) * 4;
-    return b;
-}
-template <int D, int LDP>
-__device__ __forceinline__ f32x4 rm_ld(const AccBuf& b, int v, int coff = 0) {
-    const int so = (v * (1024 / D) * LDP + coff) * 4;
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.vo, so, 0));
-}
-template <int D, int LDP>
-__device__ __forceinline__ void rm_st(const AccBuf& b, int v, f32x4 x, int coff = 0) {
-    // The slot offset rides in the voffset here, not in an SGPR soffset: a 16-byte buffer store with a register
-    // soffset still reads its data VGPRs when the next instruction issues, hipcc (ROCm 7.2) schedules a VALU
-    // write of those VGPRs right behind it without the wait state, and the stored row arrives corrupted
-    // (seen on gfx950: two of the four dwords replaced by the following v_pk_mul's result).
-    const int so = (v * (1024 / D) * LDP + coff) * 4;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), b.rs, b.vo + so, 0, 0);
-}
-
-#define FZ_FOR_ACC _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) if (rb < nrb) _Pragma("unroll") for (int reg = 0; reg < 16; ++reg)
-
-// This wave's place in a tile of `nblk` live 32-row blocks.  Group g (waves 4 g .. 4 g + 3) owns blocks 2 g, 2 g + 1 in every
-// phase; a group without a live block leaves after the tile load (all four waves: the group counters and the row-major
-// I/O of a half tile count on whole groups).  nrb = this wave's live row blocks:
-//   D = 128: wave row wr in {0, 1} owns blocks 2 wr, 2 wr + 1 (RB = 2);  D = 64: wave row wr in 0..3 owns block wr (RB = 1).
-template <int D>
-__device__ __forceinline__ int fz_live(int nblk, int wr) {
-    constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
-    const int live = nblk - wr * RB;
-    return live < 0 ? 0 : (live > RB ? RB : live);
-}
-// (VAR == false -- whole 128-row tiles, no table -- folds every one of these to a constant)
-#define FZ_TILE_SETUP()                                                          \
-    const int tile = blockIdx.x + a.tile0;                                      \
-    const int row0 = VAR ? a.mt_row0[tile] : tile * FZ_R;                       \
-    const int nblk = VAR ? a.mt_nblk[tile] : 4;                                 \
-    const int nrows = VAR ? nblk * 32 : FZ_R;                                   \
-    const int nrb = VAR ? fz_live<D>(nblk, wr) : RB;                            \
-    const bool grp_live = VAR ? nblk > 2 * grp : true
-
-#define FZ_GSYNC() grp_sync(gs)
+#include "bmp_tile.h"
 
 // SAVE == false: forward-only evaluation (m, r|z, c are not kept).  The epilogues' arithmetic is written with explicit fused
 // multiply-adds so that both instances round alike: predict's logits are bit for bit the training forward's.
@@ -947,7 +682,10 @@ __global__ __launch_bounds__(512) void k_readout_tile_fwd(ROArgs a) {
 // ---------------------------------------------------------------------------------------------
 static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 4 + 132 + 2 * FZ_ECAP + FZ_NSYNC) * sizeof(float); }
 
-extern "C" int bmp_ggnn_step_supported(int d) { return d == 64 || d == 128; }
+// d = 64 / 128: the 512-thread tile kernels of this file; d = 32: one wave per 32-row block (bmp_fused_small.hip)
+static bool fz_wide(int d) { return d == 64 || d == 128; }
+int bmp_launch_step_small(bool bwd, const StepArgs& a, int n_tiles, int d, hipStream_t st);
+extern "C" int bmp_ggnn_step_supported(int d) { return fz_wide(d) || d == 32; }
 
 // `rows`: rows the launch works on (flop / byte accounting of the roofline leg: with a tile table the live rows, passed by the caller).
 template <int D, bool FIRST, bool VAR>
@@ -998,6 +736,7 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, 
     BMP_REQUIRE((mt_row0 != nullptr) == (mt_nblk != nullptr));
     a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
+    if (!fz_wide(d)) return bmp_launch_step_small(false, a, n_tiles, d, st);
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
 
@@ -1012,7 +751,7 @@ extern "C" int bmp_ggnn_steps_fwd(const float* h, int tile0, int n_tiles, int d,
                                   const float* const* AT, const float* UcT, const float* const* b, float* const* m,
                                   float* const* rz, float* const* c, float* const* hout, const int* mt_row0, const int* mt_nblk,
                                   int mt_rows, hipStream_t st) {
-    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d) && T >= 1 && T <= FZ_TMAX);
+    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && fz_wide(d) && T >= 1 && T <= FZ_TMAX);
     BMP_REQUIRE(WT && bE && AT && b && hout && UcT && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     StepArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
@@ -1039,6 +778,7 @@ extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float
     StepArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
+    if (!fz_wide(d)) return bmp_launch_step_small(true, a, n_tiles, d, st);
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
 
@@ -1111,7 +851,7 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
 }
 
 // ---- fused RelGCN layer (d_in == d_out in {64, 128}) ----
-extern "C" int bmp_relgcn_layer_supported(int d_in, int d_out) { return d_in == d_out && bmp_ggnn_step_supported(d_in); }
+extern "C" int bmp_relgcn_layer_supported(int d_in, int d_out) { return d_in == d_out && fz_wide(d_in); }
 
 template <int D, bool VAR>
 static int rel_launch2(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
@@ -1135,7 +875,7 @@ static int rel_launch(bool bwd, const RelArgs& a, int n_tiles, hipStream_t st) {
 extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const int* csr_ptr, const int* csr_col,
                                     const float* csr_val, const float* WT, const float* bE, const float* WsT, const float* bs,
                                     int act, float* out, float* wdeg, const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
-    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
+    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && fz_wide(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.act = act; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.h = h; a.WT = WT; a.bE = bE; a.WsT = WsT; a.bs = bs; a.out = out; a.wdeg = wdeg;
@@ -1146,7 +886,7 @@ extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int 
 extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                                     const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
                                     float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
-    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
+    BMP_REQUIRE(n_tiles > 0 && fz_wide(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.dout = dout; a.y = out; a.Wnat = Wnat; a.Ws = Ws; a.dh = dh; a.gda = gda;
@@ -1194,7 +934,7 @@ extern "C" int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const f
 
 // ---- readout forward on the tile machinery (d == o in {64, 128}; h0 absent or d wide) ----
 extern "C" int bmp_readout_tile_supported(int d, int d0, int o) {
-    return bmp_ggnn_step_supported(d) && o == d && (d0 == 0 || d0 == d);
+    return fz_wide(d) && o == d && (d0 == 0 || d0 == d);
 }
 
 static size_t ro_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + 400 + FZ_R) * sizeof(float); }
@@ -1214,7 +954,7 @@ static int ro_launch(const ROArgs& a, int n_tiles, hipStream_t st) {
 extern "C" int bmp_readout_tile_fwd(const float* h, const float* h0, int n_tiles, int d, const float* WT, const float* b,
                                     int act_j, const float* row_w, const int* row_mol, const int* mol_nrows, float* ij,
                                     float* g, hipStream_t st) {
-    BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && row_mol != nullptr);
+    BMP_REQUIRE(n_tiles > 0 && fz_wide(d) && row_mol != nullptr);
     ROArgs a{h, h0, WT, b, act_j, row_w, row_mol, mol_nrows, ij, g};
     if (d == 128) return h0 ? ro_launch<128, true>(a, n_tiles, st) : ro_launch<128, false>(a, n_tiles, st);
     return h0 ? ro_launch<64, true>(a, n_tiles, st) : ro_launch<64, false>(a, n_tiles, st);

@@ -535,9 +535,10 @@ def sigmoid_cross_entropy(y: Tensor, t: Tensor) -> Tensor:
 def pair_forward(p: Params, atoms_1: Tensor, adjs_1: Tensor, atoms_2: Tensor, adjs_2: Tensor, *,
                  encoder: str = "ggnn", n_layers: int = 4, weight_tying: bool = True,
                  attn: Optional[str] = "nie", attn_activation: str = "tanh",
-                 mlp_hidden: int = 2, scale_adj: bool = True) -> Tuple[Tensor, Tensor, Tensor]:
+                 mlp_hidden: int = 2, scale_adj: bool = True, sim_method: str = "mlp") -> Tuple[Tensor, Tensor, Tensor]:
     """GraphConvPredictorForPair.__call__: with co-attention train_binary.py:84-118
-    (= eval_coattention.py:66-100); without train_ddi_modify.py:66-77.
+    (= eval_coattention.py:66-100); without train_ddi_modify.py:66-77.  ``sim_method``: the link predictor selected by
+    set_up_predictor (train_binary.py:165-187) and dispatched on by class name in __call__ (:98-116).
     Returns (logits, g1, g2) with g1/g2 the vectors fed to the link predictor."""
     def enc(a, adj):
         if encoder == "ggnn":
@@ -572,7 +573,11 @@ def pair_forward(p: Params, atoms_1: Tensor, adjs_1: Tensor, atoms_2: Tensor, ad
         g1, g2 = bimpm_coattention(p, at1, at2, prefix="attn/")
     elif attn is not None:
         raise ValueError(attn)
-    y = mlp_forward(p, torch.cat((g1, g2), dim=-1), mlp_hidden)
+    if sim_method == "mlp":                                          # train_binary.py:98-101
+        y = mlp_forward(p, torch.cat((g1, g2), dim=-1), mlp_hidden)
+    else:                                                            # :102-113: self.mlp(g1, g2)
+        fwd = {"ntn": ntn_forward, "hole": hole_forward, "symmlp": symmlp_forward, "dist-mult": distmult_forward}[sim_method]
+        y = fwd(p, g1, g2, mlp_hidden, prefix="mlp/")
     return y, g1, g2
 
 
@@ -727,7 +732,7 @@ def init_link(dr: _Draw, prefix: str, kind: str, fp_dim: int, out_dim: int, hidd
 def make_pair_params(seed: int = 777, *, encoder: str = "ggnn", hidden_dim: int = 16, out_dim: int = 16,
                      n_layers: int = 2, weight_tying: bool = True, attn: Optional[str] = "nie", head: int = 8,
                      class_num: int = 1, mlp_hidden: Sequence[int] = (32, 16),
-                     dtype: torch.dtype = torch.float64, bias_scale: float = 0.1) -> Params:
+                     dtype: torch.dtype = torch.float64, bias_scale: float = 0.1, sim_method: str = "mlp") -> Params:
     """Whole GraphConvPredictorForPair parameter set in a fixed draw order
     (graph_conv, attn, mlp) from RandomState(seed) (seed default train_ddi_modify.py:227)."""
     dr = _Draw(seed, dtype, bias_scale)
@@ -759,7 +764,10 @@ def make_pair_params(seed: int = 777, *, encoder: str = "ggnn", hidden_dim: int 
         init_bimpm(dr, "attn/", hidden_dim, head)                     # train_binary.py:255: head = fp_out_dim there
         init_mlp(dr, "mlp/", 2 * 3 * head, class_num, mlp_hidden)     # three matchings of `head` perspectives per side
         return dr.p
-    init_mlp(dr, "mlp/", 2 * out_dim, class_num, mlp_hidden)
+    if sim_method == "mlp":
+        init_mlp(dr, "mlp/", 2 * out_dim, class_num, mlp_hidden)
+    else:                                                            # train_binary.py:170-186
+        init_link(dr, "mlp/", {"dist-mult": "distmult"}.get(sim_method, sim_method), out_dim, class_num, mlp_hidden)
     return dr.p
 
 

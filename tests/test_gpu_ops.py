@@ -294,10 +294,12 @@ def test_unsupported_options_raise():
 
 
 # --------------------------------------------------------------------------------- fused step kernel
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d", [32, 64, 128])
 @pytest.mark.parametrize("first", [True, False])
 def test_fused_step_fwd_bwd(fn, batch, d, first):
-    """bmp_ggnn_step_* (message + GRU in one kernel per tile) vs the packed float64 restatement."""
+    """bmp_ggnn_step_* (message + GRU in one kernel per tile) vs the packed float64 restatement.  d = 32: the one-wave-per-block
+    kernels of bmp_fused_small.hip (the width of the reference's published models, DDI.md:6)."""
+    assert fn.step_supported(d)
     _, _, _, pb = batch
     pbd = to_dev(pb)
     dr = O._Draw(d + 7 * int(first), torch.float64, 0.3)
@@ -352,7 +354,7 @@ def test_fused_and_unfused_encoders_agree(fn, batch):
 
 
 @pytest.mark.parametrize("d,o,n_layers,tying,fused", [(64, 32, 3, True, True), (128, 128, 2, True, False),
-                                                      (64, 64, 2, False, True)])
+                                                      (64, 64, 2, False, True), (32, 16, 8, False, True), (32, 32, 3, True, True)])
 def test_ggnn_encoder_fused_variants(fn, batch, d, o, n_layers, tying, fused):
     store, i1, i2, pb = batch
     pbd = to_dev(pb)

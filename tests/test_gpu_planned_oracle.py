@@ -15,11 +15,11 @@ TOL = 1e-4
 from parity_util import close as _close      # asserts AND logs the achieved relative error
 
 
-def _oracle_step(p, batch, encoder, n_layers, attn, alpha):
+def _oracle_step(p, batch, encoder, n_layers, attn, alpha, **fwd_kw):
     from oracle import ref_cpu as O
     a1, j1, a2, j2, lab = batch
     p = {k: v.clone().requires_grad_() for k, v in p.items()}
-    y, _, _ = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), encoder=encoder, n_layers=n_layers, attn=attn)
+    y, _, _ = O.pair_forward(p, T(a1), T(j1).double(), T(a2), T(j2).double(), encoder=encoder, n_layers=n_layers, attn=attn, **fwd_kw)
     loss = O.sigmoid_cross_entropy(y, T(lab))
     names = sorted(p)
     grads = torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True)
@@ -78,6 +78,57 @@ def test_planned_training_step_matches_oracle_at_d128(encoder, n_layers):
         if big.any():
             assert (upd - upd_o)[big].abs().max().item() <= 1e-3 * alpha, name
         off += n
+
+
+@pytest.mark.parametrize("layout", ["instance", "encoder"])
+@pytest.mark.parametrize("sim_method", ["ntn", "hole"])
+def test_planned_reference_headline_model_matches_oracle(sim_method, layout):
+    """The model every figure of the reference was trained with (DDI.md:6, RECORD.txt:246-251; train_binary.py:165-187,226-227):
+    GGNN hidden 32, 8 propagation steps, weight_tying=False, fp_out_dim 16 (the script's default) + NieFineCoattention(32, 16,
+    head=8, tanh) + NTN / HolE with --net-hidden-dims= (no hidden layer), batch 32 -- through the PLANNED path
+    (functional_loss: the d = 32 fused step kernels of bmp_fused_small.hip, the pair kernels, the link predictor's kernels),
+    per-instance batches and the encoder layout (tile table: blocks of 1..4 live 32-row blocks), against the dense float64
+    oracle: logits, loss, every gradient at 2e-5 of the tensor's max-abs."""
+    from bmp import enclayout, packed, synth
+    from bmp import functional as Fn
+    from bmp.dp import FlatAdam
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    store = synth.make_store(60, seed=23, n_lo=3, n_hi=70, n_mean=22)
+    ms = packed.MolStore(store)
+    rs = np.random.RandomState(8)
+    B = 32
+    i1, i2 = rs.randint(0, 60, B), rs.randint(0, 60, B)
+    lab = rs.randint(0, 2, (B, 1)).astype(np.int32)
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    kw = dict(hidden_dim=32, out_dim=16, n_layers=8, weight_tying=False, attn="nie", head=8, sim_method=sim_method, mlp_hidden=())
+    p = O.make_pair_params(777, encoder="ggnn", dtype=torch.float64, bias_scale=0.05, **kw)
+    y_o, loss_o, g_o, _ = _oracle_step(p, (a1, j1, a2, j2, lab), "ggnn", 8, "nie", 1e-3, weight_tying=False, sim_method=sim_method,
+                                       mlp_hidden=0)
+    model = build_pair_predictor(encoder="ggnn", **kw).to(dev)
+    load_param_dict(model, p)
+    opt = FlatAdam(model, alpha=1e-3)
+    ds = packed.DeviceMolStore(ms, dev)
+    if layout == "encoder":
+        pb, t = enclayout.encode_from_store_device(ds, [i1, i2], labels=lab)
+    else:
+        pb, t = packed.pack_from_store_device(ds, [i1, i2], labels=lab)
+    assert Fn.step_supported(32)
+    for rep in range(2):
+        loss = opt.functional_loss(pb, t=t)
+        assert opt.plan is not None and {"graph_conv.", "attn."} <= set(opt.plan.P) and model.graph_conv._plan_fused()
+        loss.backward()
+        opt.collect_grads()
+        _close(model.y, y_o, f"logits ({sim_method}, {layout}, rep {rep})", tol=2e-5)
+        _close(loss, loss_o, f"loss ({sim_method}, {layout}, rep {rep})", tol=2e-5)
+        off = 0
+        for name, shp in zip(opt.names, opt.shapes):
+            n = int(np.prod(shp))
+            _close(opt.grad[off:off + n].view(shp), g_o[name.replace(".", "/")], f"grad {name} ({sim_method}, {layout}, rep {rep})",
+                   tol=2e-5)
+            off += n
 
 
 def test_planned_c4_step_matches_oracle_at_d256():
