@@ -685,6 +685,9 @@ static size_t fz_lds_bytes(int D) { return ((size_t)2 * FZ_R * (D + 4) + FZ_R * 
 // d = 64 / 128: the 512-thread tile kernels of this file; d = 32: one wave per 32-row block (bmp_fused_small.hip)
 static bool fz_wide(int d) { return d == 64 || d == 128; }
 int bmp_launch_step_small(bool bwd, const StepArgs& a, int n_tiles, int d, hipStream_t st);
+size_t bmp_step_wgrad_small_ws_floats(int N, int d);
+int bmp_launch_step_wgrad_small(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first, float* o1,
+                                float* o2, float* dUcT, float* cs, int accumulate, float* ws, hipStream_t st);
 extern "C" int bmp_ggnn_step_supported(int d) { return fz_wide(d) || d == 32; }
 
 // `rows`: rows the launch works on (flop / byte accounting of the roofline leg: with a tile table the live rows, passed by the caller).
@@ -804,6 +807,7 @@ static bool step_wgrad_fusable(int N, int d) { return (d == 64 || d == 128) && (
 
 extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
     size_t a = bmp_wgrad_ws_floats(N, d, 7 * d);
+    if (d == 32 && (N & 7) == 0) { const size_t b = bmp_step_wgrad_small_ws_floats(N, d); if (b > a) a = b; }
     if (step_wgrad_fusable(N, d)) {
         WGArgs g[3];
         const int n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0);
@@ -826,6 +830,8 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
     BMP_REQUIRE(h && m && rz && gda && o1 && o2 && dUcT && cs && ws);
     static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;        // A/B switch (tools, tests)
+    if (!unfused && d == 32 && (N & 7) == 0 && ((uintptr_t)gda & 15) == 0)          // one 32-row MFMA block per output: bmp_fused_small.hip
+        return bmp_launch_step_wgrad_small(h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate, ws, st);
     if (!unfused && step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)rz & 15) == 0 &&
         ((uintptr_t)gda & 15) == 0) {
         WGArgs g[3];

@@ -393,3 +393,147 @@ int bmp_launch_step_small(bool bwd, const StepArgs& a, int n_tiles, int d, hipSt
         return a.first ? fs_launch3<32, true, true>(bwd, a, n_tiles, rows, st) : fs_launch3<32, false, true>(bwd, a, n_tiles, rows, st);
     return a.first ? fs_launch3<32, true, false>(bwd, a, n_tiles, rows, st) : fs_launch3<32, false, false>(bwd, a, n_tiles, rows, st);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradients of one d = 32 step (bmp_ggnn_step_wgrad):  o1 [D x 7D] = h^T gda, o2 [D x 3D] = m^T gda[:, 4D:],
+// dUcT [D x D] = (r*h)^T gda[:, 6D:], cs [7D] = column sums of gda -- reductions over all N rows of outputs that are ONE
+// 32-row MFMA block tall.  The general weight-gradient GEMM (128 x 128 output tiles staged through LDS, bmp_gemm.hip) spends a
+// d = 32 step on padding: three launches + three slab folds + a column-sum pass, 170 us per step of the reference's published
+// model, more than the step's forward and backward kernels together.  Here the operands go straight from global memory into the
+// MFMA registers -- a row of X is the A fragment of the transposed product as it lies in memory, and NB consecutive columns
+// of gda per lane are NB B fragments whose output columns are interleaved (column NB * lane + t: undone by the store, which
+// is NB consecutive floats per lane again) -- so every byte of gda is read once, by one wave, in 16-byte pieces:
+//   wave 0: o1[:, 0:4D]   (A = h,   B = the four G blocks, one dwordx4 per lane and row pair) + their column sums
+//   wave 1: o1[:, 4D:7D]  (A = h,   B = da_r | da_z | da_c) + their column sums
+//   wave 2: o2            (A = m,   B = the same three blocks)
+//   wave 3: dUcT          (A = r*h, B = da_c)
+// The first call after reset has no r gate: the da_r columns of gda are not written by the backward and are not read here.
+// Rows are split over at most 256 workgroups; partial results go to the workspace in the outputs' own layout and are folded
+// in workgroup order by k_step_wgrad_fold_s (bitwise reproducible; accumulate adds into the outputs: tied layers).
+// ---------------------------------------------------------------------------------------------
+template <int NB> struct FsVec;
+template <> struct FsVec<1> { typedef float T; };
+template <> struct FsVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct FsVec<4> { typedef f32x4 T; };
+struct __attribute__((packed, aligned(4))) FsF3 { float v[3]; };
+template <int NB> __device__ __forceinline__ void fs_ldv(const float* p, float (&o)[NB]) {
+    if constexpr (NB == 3) { const FsF3 x = *(const FsF3*)p; o[0] = x.v[0]; o[1] = x.v[1]; o[2] = x.v[2]; }
+    else if constexpr (NB == 1) { o[0] = *p; }
+    else { const typename FsVec<NB>::T x = *(const typename FsVec<NB>::T*)p;
+#pragma unroll
+           for (int t = 0; t < NB; ++t) o[t] = x[t]; }
+}
+template <int NB> __device__ __forceinline__ void fs_stv(float* p, const float (&o)[NB]) {
+    if constexpr (NB == 3) { FsF3 x; x.v[0] = o[0]; x.v[1] = o[1]; x.v[2] = o[2]; *(FsF3*)p = x; }
+    else if constexpr (NB == 1) { *p = o[0]; }
+    else { typename FsVec<NB>::T x;
+#pragma unroll
+           for (int t = 0; t < NB; ++t) x[t] = o[t];
+           *(typename FsVec<NB>::T*)p = x; }
+}
+
+// out[i, NB*j + t] (i, j < 32) = sum over rows r0 <= r < r1 of X[r, i] (* X2[r, i]) * G[r, NB*j + t];  cs[NB*j + t] = sum of G[r, .]
+template <int D, int NB, bool X2, bool CS>
+__device__ __forceinline__ void fs_wgrad_job(const float* X, int ldx, const float* Xb, int ldxb, const float* G, int ldg, int r0, int r1,
+                                             float* out, int ldo, float* cs) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    f32x16 acc[NB];
+    float csum[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { csum[t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f; }
+    for (int r = r0; r < r1; r += 8) {               // four MFMA k-steps (two rows each) per trip, all loads first
+        float a[4], b[4][NB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t row = (size_t)(r + 2 * u + hi);
+            a[u] = X[row * ldx + l31];
+            if (X2) a[u] *= Xb[row * ldxb + l31];
+            fs_ldv<NB>(G + row * ldg + NB * l31, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                acc[t] = bmp_mfma(a[u], b[u][t], acc[t]);
+                if (CS) csum[t] += b[u][t];
+            }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+        float o[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) o[t] = acc[t][reg];
+        fs_stv<NB>(out + (size_t)i * ldo + NB * l31, o);
+    }
+    if (CS) {
+        float o[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) o[t] = csum[t] + __shfl_xor(csum[t], 32);      // rows of even + odd parity, fixed order
+        if (hi == 0) fs_stv<NB>(cs + NB * l31, o);
+    }
+}
+
+#define FSW_PART(D) ((D) * 7 * (D) + (D) * 3 * (D) + (D) * (D) + 7 * (D))      // o1 | o2 | dUcT | cs
+
+template <int D, bool FIRST>
+__global__ __launch_bounds__(256) void k_step_wgrad_s(const float* __restrict__ h, const float* __restrict__ m, const float* __restrict__ rz,
+                                                      const float* __restrict__ gda, int N, int rps, float* __restrict__ ws) {
+    const int w = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rps, r1 = r0 + rps < N ? r0 + rps : N;
+    float* part = ws + (size_t)blockIdx.x * FSW_PART(D);
+    float* p_o1 = part, *p_o2 = part + D * 7 * D, *p_u = p_o2 + D * 3 * D, *p_cs = p_u + D * D;
+    constexpr int LG = 7 * D;
+    if (w == 0) fs_wgrad_job<D, 4, false, true>(h, D, nullptr, 0, gda, LG, r0, r1, p_o1, LG, p_cs);
+    else if (w == 1) {
+        if (FIRST) fs_wgrad_job<D, 2, false, true>(h, D, nullptr, 0, gda + 5 * D, LG, r0, r1, p_o1 + 5 * D, LG, p_cs + 5 * D);
+        else fs_wgrad_job<D, 3, false, true>(h, D, nullptr, 0, gda + 4 * D, LG, r0, r1, p_o1 + 4 * D, LG, p_cs + 4 * D);
+    } else if (w == 2) {
+        if (FIRST) fs_wgrad_job<D, 2, false, false>(m, D, nullptr, 0, gda + 5 * D, LG, r0, r1, p_o2 + D, 3 * D, nullptr);
+        else fs_wgrad_job<D, 3, false, false>(m, D, nullptr, 0, gda + 4 * D, LG, r0, r1, p_o2, 3 * D, nullptr);
+    } else if (!FIRST) {
+        fs_wgrad_job<D, 1, true, false>(rz, 2 * D, h, D, gda + 6 * D, LG, r0, r1, p_u, D, nullptr);       // A = r * h
+    }
+}
+
+// out (=|+=) sum over the G partials, in workgroup order.  first: the da_r parts (o1[:, 4D:5D], o2[:, 0:D], dUcT, cs[4D:5D]) were
+// not computed and count as zeros.
+template <int D>
+__global__ __launch_bounds__(256) void k_step_wgrad_fold_s(const float* __restrict__ ws, int G, int first, int accumulate,
+                                                           float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ dUcT,
+                                                           float* __restrict__ cs) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= FSW_PART(D)) return;
+    float* dst; bool live = true;
+    if (idx < D * 7 * D) { const int c = idx % (7 * D); dst = o1 + idx; live = !(first && c >= 4 * D && c < 5 * D); }
+    else if (idx < D * 10 * D) { const int k = idx - D * 7 * D; dst = o2 + k; live = !(first && (k % (3 * D)) < D); }
+    else if (idx < D * 11 * D) { dst = dUcT + (idx - D * 10 * D); live = !first; }
+    else { const int c = idx - D * 11 * D; dst = cs + c; live = !(first && c >= 4 * D && c < 5 * D); }
+    float acc = 0.f;
+    if (live) for (int g = 0; g < G; ++g) acc += ws[(size_t)g * FSW_PART(D) + idx];
+    *dst = accumulate ? *dst + acc : acc;
+}
+
+static void fsw_plan(int N, int& G, int& rps) {
+    rps = 8 * ((N + 8 * 256 - 1) / (8 * 256));
+    G = (N + rps - 1) / rps;
+}
+size_t bmp_step_wgrad_small_ws_floats(int N, int d) {
+    int G, rps; fsw_plan(N, G, rps);
+    return (size_t)G * FSW_PART(32);
+}
+int bmp_launch_step_wgrad_small(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first, float* o1,
+                                float* o2, float* dUcT, float* cs, int accumulate, float* ws, hipStream_t st) {
+    BMP_REQUIRE(d == 32 && N > 0 && (N & 7) == 0);
+    int G, rps; fsw_plan(N, G, rps);
+    const double cols = first ? 6.0 + 2.0 : 7.0 + 3.0 + 1.0;
+    BmpProfScope prof(BMP_KCLS_WGRAD, 2.0 * N * d * cols * d, 4.0 * N * d * (7.0 + 3.0), st, BMP_KID_WGRAD_STEP);
+    if (first) hipLaunchKernelGGL((k_step_wgrad_s<32, true>), dim3(G), dim3(256), 0, st, h, m, rz, gda, N, rps, ws);
+    else hipLaunchKernelGGL((k_step_wgrad_s<32, false>), dim3(G), dim3(256), 0, st, h, m, rz, gda, N, rps, ws);
+    BMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_step_wgrad_fold_s<32>), dim3((FSW_PART(32) + 255) / 256), dim3(256), 0, st, ws, G, first, accumulate, o1, o2, dUcT, cs);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}

@@ -194,37 +194,59 @@ __global__ __launch_bounds__(256) void k_pf_ntn_bwd_x(const float* __restrict__ 
 }
 // workgroup p: dW[p, q, o] = sum_b x1[b,p] x2[b,q] g[b,o]; dV1[p, o] = sum_b x1[b,p] g[b,o];
 // workgroups p < d2 also dV2[p, o] = sum_b x2[b,p] g[b,o]; workgroup 0 also db[o] = sum_b g[b,o].  Rows in order.
+// The rows come through LDS in chunks of PF_WR (x1's column p, the chunk's x2 and g rows): round 3's form walked the B rows
+// from global memory inside every thread's sum -- three dependent strided loads per multiply-add, 437 us for 1024 pairs of
+// the reference's published model (d1 = d2 = 16, K = 8).  Same sums in the same order.
+#define PF_WR 32
 __global__ __launch_bounds__(256) void k_pf_ntn_bwd_w(const float* __restrict__ g, const float* __restrict__ x1,
                                                       const float* __restrict__ x2, int B, int d1, int d2, int K,
                                                       float* __restrict__ dW, float* __restrict__ dV1,
                                                       float* __restrict__ dV2, float* __restrict__ db) {
-    const int p = blockIdx.x;
-    if (p < d1) {
-        for (int idx = threadIdx.x; idx < d2 * K; idx += 256) {
-            const int q = idx / K, o = idx % K;
-            float acc = 0.f;
-            for (int b = 0; b < B; ++b) acc += x1[(size_t)b * d1 + p] * x2[(size_t)b * d2 + q] * g[(size_t)b * K + o];
-            dW[((size_t)p * d2 + q) * K + o] = acc;
-        }
-        if (dV1)
-            for (int o = threadIdx.x; o < K; o += 256) {
-                float acc = 0.f;
-                for (int b = 0; b < B; ++b) acc += x1[(size_t)b * d1 + p] * g[(size_t)b * K + o];
-                dV1[(size_t)p * K + o] = acc;
+    extern __shared__ float pf_lds[];
+    float* sx1 = pf_lds;                       // [PF_WR]           x1[b, p]
+    float* sx2 = sx1 + PF_WR;                  // [PF_WR x d2]
+    float* sg = sx2 + PF_WR * d2;              // [PF_WR x K]
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int nW = p < d1 ? d2 * K : 0;        // outputs of dW owned by this workgroup
+    constexpr int MAXO = (PF_MAXD / 4) * PF_MAXK / 256;      // dW outputs per thread
+    float accW[MAXO];
+#pragma unroll
+    for (int t = 0; t < MAXO; ++t) accW[t] = 0.f;
+    float accV1 = 0.f, accV2 = 0.f, accB = 0.f;
+    for (int b0 = 0; b0 < B; b0 += PF_WR) {
+        const int nr = B - b0 < PF_WR ? B - b0 : PF_WR;
+        __syncthreads();
+        if (p < d1) for (int i = tid; i < nr; i += 256) sx1[i] = x1[(size_t)(b0 + i) * d1 + p];
+        for (int i = tid; i < nr * d2; i += 256) sx2[i] = x2[(size_t)b0 * d2 + i];
+        for (int i = tid; i < nr * K; i += 256) sg[i] = g[(size_t)b0 * K + i];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MAXO; ++t) {
+            const int idx = tid + 256 * t;
+            if (idx < nW) {
+                const int q = idx / K, o = idx % K;
+                float acc = accW[t];
+                for (int b = 0; b < nr; ++b) acc += sx1[b] * sx2[b * d2 + q] * sg[b * K + o];
+                accW[t] = acc;
             }
+        }
+        if (tid < K) {
+            const int o = tid;
+            if (dV1 && p < d1) for (int b = 0; b < nr; ++b) accV1 += sx1[b] * sg[b * K + o];
+            if (dV2 && p < d2) for (int b = 0; b < nr; ++b) accV2 += sx2[b * d2 + p] * sg[b * K + o];
+            if (db && p == 0) for (int b = 0; b < nr; ++b) accB += sg[b * K + o];
+        }
     }
-    if (dV2 && p < d2)
-        for (int o = threadIdx.x; o < K; o += 256) {
-            float acc = 0.f;
-            for (int b = 0; b < B; ++b) acc += x2[(size_t)b * d2 + p] * g[(size_t)b * K + o];
-            dV2[(size_t)p * K + o] = acc;
-        }
-    if (db && p == 0)
-        for (int o = threadIdx.x; o < K; o += 256) {
-            float acc = 0.f;
-            for (int b = 0; b < B; ++b) acc += g[(size_t)b * K + o];
-            db[o] = acc;
-        }
+#pragma unroll
+    for (int t = 0; t < MAXO; ++t) {
+        const int idx = tid + 256 * t;
+        if (idx < nW) dW[(size_t)p * d2 * K + idx] = accW[t];
+    }
+    if (tid < K) {
+        if (dV1 && p < d1) dV1[(size_t)p * K + tid] = accV1;
+        if (dV2 && p < d2) dV2[(size_t)p * K + tid] = accV2;
+        if (db && p == 0) db[tid] = accB;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -287,7 +309,8 @@ extern "C" int bmp_pairfeat_bwd(int kind, const float* dout, const float* x1, co
             hipLaunchKernelGGL(k_pf_ntn_bwd_x, dim3((B + PF_RB - 1) / PF_RB), dim3(256), 0, st, dout, x1, x2, B, d1, d2, W, V1, V2, K, dx1, dx2);
             BMP_LAUNCH_CHECK();
             const int nb = d1 > d2 ? d1 : d2;
-            hipLaunchKernelGGL(k_pf_ntn_bwd_w, dim3(nb), dim3(256), 0, st, dout, x1, x2, B, d1, d2, K, dW, dV1, dV2, db);
+            hipLaunchKernelGGL(k_pf_ntn_bwd_w, dim3(nb), dim3(256), (size_t)PF_WR * (1 + d2 + K) * sizeof(float), st, dout, x1, x2, B, d1, d2,
+                               K, dW, dV1, dV2, db);
             break;
         }
         default: return -1;
