@@ -47,7 +47,66 @@ struct CoArgs {
     // cleared the arrays
     const int* rm1; const int* rm2; int N1, N2;
     const float* gscale;                       // backward: device scalar dout1 / dout2 are multiplied with on load (null: 1)
+    // the projections of the pair's own rows, computed by the pair's workgroup (co_project): forward Q2 = X2 . WbT,
+    // Z_k = X_k . ZW_kT + zb_k; backward dX1 += dZ1 . ZW1, dX2 = dQ2 . Wb + dZ2 . ZW2
+    const float* WbT; const float* ZW1T; const float* ZW2T; const float* zb1; const float* zb2;      // [d x d], [d x ZC], [ZC]
+    const float* Wb; const float* ZW1; const float* ZW2;                                             // [d x d], [ZC x d]
+    float* Q2w; float* Z1w; float* Z2w;        // the forward's writable views of Q2 / Z1 / Z2
+    float* dX2;                                // [N2 x d]
 };
+
+// Row projections of ONE molecule's rows on the matrix cores, inside the pair's workgroup:
+//   Y[r + i, c] (=|+=) bias[c] + sum_s sum_k A_s[r + i, k] . B_s[k, c]      i < n, c < Nout; B_s K-major [K_s x ldb]
+// as 32 x 32 output blocks dealt to the workgroup's waves (block q of this job list = first + q; a wave takes the blocks
+// congruent to its number).  A rows come straight from global memory as 16-byte K runs (rows past n re-read row n - 1 and
+// are not stored), B as one dword per k and lane (a 128-byte line per half wave), K_s a multiple of 8.
+// Round 3 ran these as launches of their own around the pair kernels (k_rowgemm_multi: 56 us forward + 56 us backward per
+// step at 0.35 MFMA-busy, every operand through HBM twice); a molecule's rows belong to exactly one pair, so the pair's
+// workgroup -- which reads them anyway -- is the natural owner.
+struct CoProj {
+    const float* A[2]; int lda[2]; int K[2]; const float* B[2]; int ldb[2]; int nsrc;
+    float* Y; int ldy; int Nout; const float* bias; int r, n, accumulate;
+};
+__device__ __forceinline__ int co_proj_blocks(const CoProj& p) { return ((p.n + 31) >> 5) * ((p.Nout + 31) >> 5); }
+template <int NW>
+__device__ __forceinline__ void co_project(const CoProj& p, int first, int wave, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ncb = (p.Nout + 31) >> 5, nblk = co_proj_blocks(p);
+    int q = wave - first % NW; if (q < 0) q += NW;          // this wave's first block of the job
+    for (; q < nblk; q += NW) {
+        const int br = q / ncb, bc = q % ncb;
+        int ia = br * 32 + l31; ia = ia < p.n ? ia : p.n - 1;
+        const int col = bc * 32 + l31, colc = col < p.Nout ? col : p.Nout - 1;
+        f32x16 acc;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        for (int s = 0; s < p.nsrc; ++s) {
+            const float* ap = p.A[s] + (size_t)(p.r + ia) * p.lda[s] + 4 * hi;
+            const float* bp = p.B[s] + (size_t)(4 * hi) * p.ldb[s] + colc;
+            const int ldb = p.ldb[s];
+#pragma unroll 4
+            for (int k0 = 0; k0 < p.K[s]; k0 += 8) {
+                const f32x4 av = *(const f32x4*)(ap + k0);
+                float bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = bp[(size_t)(k0 + t) * ldb];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = bmp_mfma(av[t], bv[t], acc);
+            }
+        }
+        if (col < p.Nout) {
+            const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rr = br * 32 + bmp_acc_row(reg, lane);
+                if (rr < p.n) {
+                    float* y = p.Y + (size_t)(p.r + rr) * p.ldy + col;
+                    *y = (p.accumulate ? *y : 0.f) + (acc[reg] + bias);
+                }
+            }
+        }
+    }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -228,6 +287,18 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     const CoLds L = BIG ? co_carve(a.big_ws + (size_t)blockIdx.x * a.big_stride, a.np, ldc, H, false, 0, NT, true)
                         : co_carve(lds_raw, a.np, ldc, H, false);
     const float cb = a.cbias[0];
+
+    // ---- the pair's projections: Q2 = X2 . WbT, Z1 = X1 . ZW1T + zb, Z2 = X2 . ZW2T + zb (kept for the backward) ----
+    if (a.WbT != nullptr) {
+        CoProj pz1{{a.X1, nullptr}, {d, 0}, {d, 0}, {a.ZW1T, nullptr}, {ZC, 0}, 1, a.Z1w, ZC, ZC, a.zb1, r1, n1, 0};
+        CoProj pq2{{a.X2, nullptr}, {d, 0}, {d, 0}, {a.WbT, nullptr}, {d, 0}, 1, a.Q2w, d, d, nullptr, r2, n2, 0};
+        CoProj pz2{{a.X2, nullptr}, {d, 0}, {d, 0}, {a.ZW2T, nullptr}, {ZC, 0}, 1, a.Z2w, ZC, ZC, a.zb2, r2, n2, 0};
+        const int f1 = co_proj_blocks(pz1), f2 = f1 + co_proj_blocks(pq2);
+        co_project<NW>(pz1, 0, wave, lane);
+        co_project<NW>(pq2, f1, wave, lane);
+        co_project<NW>(pz2, f2, wave, lane);
+        __syncthreads();            // the workgroup's own global writes are visible to all of its waves from here on
+    }
 
     for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
@@ -431,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
             for (int c = tid; c < ZC; c += NT) a.dZ1[(size_t)row * ZC + c] = 0.f;
         }
         for (int row = r2 + n2; row < a.N2 && a.rm2[row] < 0; ++row) {
-            for (int c = tid; c < d; c += NT) a.dQ2[(size_t)row * d + c] = 0.f;
+            for (int c = tid; c < d; c += NT) { a.dQ2[(size_t)row * d + c] = 0.f; if (a.Wb) a.dX2[(size_t)row * d + c] = 0.f; }
             for (int c = tid; c < ZC; c += NT) a.dZ2[(size_t)row * ZC + c] = 0.f;
         }
     }
@@ -795,6 +866,14 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
             }
         }
     }
+    // ---- the projections' input gradients for the pair's own rows: dX1 += dZ1 . ZW1 ; dX2 = dQ2 . Wb + dZ2 . ZW2 ----
+    if (a.Wb != nullptr) {
+        __syncthreads();            // dQ2, dZ1, dZ2 and the energy part of dX1 of this pair are complete and visible
+        CoProj px1{{a.dZ1, nullptr}, {ZC, 0}, {ZC, 0}, {a.ZW1, nullptr}, {d, 0}, 1, a.dX1, d, d, nullptr, r1, n1, 1};
+        CoProj px2{{a.dQ2, a.dZ2}, {d, ZC}, {d, ZC}, {a.Wb, a.ZW2}, {d, d}, 2, a.dX2, d, d, nullptr, r2, n2, 0};
+        co_project<NW>(px1, 0, wave, lane);
+        co_project<NW>(px2, co_proj_blocks(px1), wave, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -849,17 +928,7 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
                 (Cbuf != nullptr) == (al2 != nullptr));
     const int ZC = bmp_coattn_zcols(o, H);
     int rc;
-    {   // Q2 = X2 . WbT ; Z1 = X1 . ZW1T + zb ; Z2 = X2 . ZW2T + zb : three projections, one launch
-        RGArgs g[3]; memset(g, 0, sizeof(g));
-        g[0].s[0] = RGSrc{X2, nullptr, WbT, d, 0, d, d};
-        g[0].nsrc = 1; g[0].Nout = d; g[0].Y = Q2; g[0].ldy = d;
-        for (int s = 0; s < 2; ++s) {
-            g[1 + s].s[0] = RGSrc{s == 0 ? X1 : X2, nullptr, s == 0 ? ZW1T : ZW2T, d, 0, ZC, d};
-            g[1 + s].nsrc = 1; g[1 + s].Nout = ZC; g[1 + s].Y = s == 0 ? Z1 : Z2; g[1 + s].ldy = ZC; g[1 + s].bias = zb + ((mode & 2) && s ? ZC : 0);
-        }
-        const int nt[3] = {n_tiles2, n_tiles1, n_tiles2};
-        if ((rc = bmp_launch_rowgemm_multi(g, nt, 3, st))) return rc;
-    }
+    // (Q2 = X2 . WbT, Z1 = X1 . ZW1T + zb, Z2 = X2 . ZW2T + zb: inside the pair kernels since round 4 -- co_project)
     const void* kf = H == 8 ? (const void*)k_coattn_fwd<8, CO_NT_FWD> : H == 4 ? (const void*)k_coattn_fwd<4, CO_NT_FWD>
                                                                               : (const void*)k_coattn_fwd<0, CO_NT_FWD>;
     if ((rc = co_set_lds(kf, 160 * 1024))) return rc;
@@ -868,6 +937,7 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
     a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode & 1; a.order = order;
     a.Cbuf = Cbuf; a.H1 = H1; a.H2 = H2; a.al1 = al1; a.al2 = al2; a.out1 = out1; a.out2 = out2;
+    a.WbT = WbT; a.ZW1T = ZW1T; a.ZW2T = ZW2T; a.zb1 = zb; a.zb2 = zb + ((mode & 2) ? ZC : 0); a.Q2w = Q2; a.Z1w = Z1; a.Z2w = Z2;
     // one launch per size class: LDS (and so the workgroups per CU) follows the pairs' actual sizes.  (The callers hand
     // the forward ONE class sized by the largest pair: its own class for a handful of big pairs, beside the others on a
     // second stream as the backward does below, measured 0.5 % slower on the C2 / C3 steps.)
@@ -963,6 +1033,10 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
     if (row_mol1 && row_mol2) { a.rm1 = row_mol1; a.rm2 = row_mol2; a.N1 = N1; a.N2 = N2; }
     a.gscale = gscale;
+    a.Wb = Wb; a.ZW1 = ZW1; a.ZW2 = ZW2; a.dX2 = dX2;
+    if (!(row_mol1 && row_mol2)) {      // without the maps the pair kernels do not know the dead rows: cleared here
+        if ((e = hipMemsetAsync(dX2, 0, (size_t)N2 * d * sizeof(float), st)) != hipSuccess) return (int)e;
+    }
     if (!st_w) st_w = st;
     {
         const int cnt[4] = {n32, n64, n96, n128};
@@ -1008,16 +1082,7 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
         if (beside && (rc = bmp_stream_after(st_w, st))) return rc;
     }
     if ((rc = bmp_fork_to(st, st_w))) return rc;        // dQ2, dZ1, dZ2, dpart are complete: the weight gradients may start
-    {   // dX1 += dZ1 . ZW1 (K = ZC) ; dX2 = dQ2 . W + dZ2 . ZW2 : one launch
-        RGArgs g[2]; memset(g, 0, sizeof(g));
-        g[0].s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};
-        g[0].nsrc = 1; g[0].Nout = d; g[0].Y = dX1; g[0].ldy = d; g[0].accumulate = 1;
-        g[1].s[0] = RGSrc{dQ2, nullptr, Wb, d, 0, d, d};
-        g[1].s[1] = RGSrc{dZ2, nullptr, ZW2, ZC, 0, d, ZC};
-        g[1].nsrc = 2; g[1].Nout = d; g[1].Y = dX2; g[1].ldy = d;
-        const int nt[2] = {n_tiles1, n_tiles2};
-        if ((rc = bmp_launch_rowgemm_multi(g, nt, 2, st))) return rc;
-    }
+    // (dX1 += dZ1 . ZW1, dX2 = dQ2 . W + dZ2 . ZW2: inside the pair kernels since round 4 -- co_project)
     {   // the three weight gradients: a few tiles each, one launch.  dzb = column sums of dZ1 and dZ2: they ride along
         // with the two GEMMs that read those arrays anyway (the second reduction accumulates into the first's result)
         const WGArgs g[3] = {WGArgs{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0, nullptr, 0, nullptr},
