@@ -47,77 +47,7 @@ struct CoArgs {
     // cleared the arrays
     const int* rm1; const int* rm2; int N1, N2;
     const float* gscale;                       // backward: device scalar dout1 / dout2 are multiplied with on load (null: 1)
-    // the projections of the pair's own rows, computed by the pair's workgroup (co_project): forward Q2 = X2 . WbT,
-    // Z_k = X_k . ZW_kT + zb_k; backward dX1 += dZ1 . ZW1, dX2 = dQ2 . Wb + dZ2 . ZW2
-    const float* WbT; const float* ZW1T; const float* ZW2T; const float* zb1; const float* zb2;      // [d x d], [d x ZC], [ZC]
-    const float* Wb; const float* ZW1; const float* ZW2;                                             // [d x d], [ZC x d]
-    float* Q2w; float* Z1w; float* Z2w;        // the forward's writable views of Q2 / Z1 / Z2
-    float* dX2;                                // [N2 x d]
-    // backward, the pooled outputs' linear part taken per MOLECULE instead of per atom (see the note at the pooled outputs):
-    float* U;                                  // [B x 2 x d]  u_s = dout_s . Wj_s (workspace)
-    float* PX1; float* PX2;                    // [B x d]      (sum_k w alpha X_k) / (sum_k w alpha): X operand of dWj
-    float* DJ1; float* DJ2;                    // [B x o]      (sum_k w alpha) * dout_s:             dY operand of dWj, dbj
 };
-
-// Row projections of ONE molecule's rows on the matrix cores, inside the pair's workgroup:
-//   Y[r + i, c] (=|+=) bias[c] + sum_s sum_k A_s[r + i, k] . B_s[k, c]      i < n, c < Nout; B_s K-major [K_s x ldb]
-// as 32 x 32 output blocks dealt to the workgroup's waves (block q of this job list = first + q; a wave takes the blocks
-// congruent to its number).  A rows come straight from global memory as 16-byte K runs (rows past n re-read row n - 1 and
-// are not stored), B as one dword per k and lane (a 128-byte line per half wave), K_s a multiple of 8.
-// Round 3 ran these as launches of their own around the pair kernels (k_rowgemm_multi: 56 us forward + 56 us backward per
-// step at 0.35 MFMA-busy, every operand through HBM twice); a molecule's rows belong to exactly one pair, so the pair's
-// workgroup -- which reads them anyway -- is the natural owner.
-struct CoProj {
-    const float* A[2]; int lda[2]; int K[2]; const float* B[2]; int ldb[2]; int nsrc;
-    float* Y; int ldy; int Nout; const float* bias; int r, n, accumulate;
-    const float* rs = nullptr; const float* uv = nullptr;      // + rs[i] * uv[c]  (a rank-1 term: LDS / global vectors)
-};
-__device__ __forceinline__ int co_proj_blocks(const CoProj& p) { return ((p.n + 31) >> 5) * ((p.Nout + 31) >> 5); }
-template <int NW>
-__device__ __forceinline__ void co_project(const CoProj& p, int first, int wave, int lane) {
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int ncb = (p.Nout + 31) >> 5, nblk = co_proj_blocks(p);
-    int q = wave - first % NW; if (q < 0) q += NW;          // this wave's first block of the job
-    for (; q < nblk; q += NW) {
-        const int br = q / ncb, bc = q % ncb;
-        int ia = br * 32 + l31; ia = ia < p.n ? ia : p.n - 1;
-        const int col = bc * 32 + l31, colc = col < p.Nout ? col : p.Nout - 1;
-        f32x16 acc;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-        for (int s = 0; s < p.nsrc; ++s) {
-            const float* ap = p.A[s] + (size_t)(p.r + ia) * p.lda[s] + 4 * hi;
-            const float* bp = p.B[s] + (size_t)(4 * hi) * p.ldb[s] + colc;
-            const int ldb = p.ldb[s];
-            const int Ks = p.K[s];                           // a multiple of 4: the upper half wave's k run may fall off the end
-#pragma unroll 4
-            for (int k0 = 0; k0 < Ks; k0 += 8) {
-                const bool kin = k0 + 4 * hi < Ks;
-                const int kk = kin ? k0 : k0 - 4;
-                f32x4 av = *(const f32x4*)(ap + kk);
-                if (!kin) av = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float bv[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) bv[t] = bp[(size_t)(kk + t) * ldb];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc = bmp_mfma(av[t], bv[t], acc);
-            }
-        }
-        if (col < p.Nout) {
-            const float bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int rr = br * 32 + bmp_acc_row(reg, lane);
-                if (rr < p.n) {
-                    float* y = p.Y + (size_t)(p.r + rr) * p.ldy + col;
-                    float v = acc[reg] + bias;
-                    if (p.rs) v += p.rs[rr] * p.uv[col];
-                    *y = (p.accumulate ? *y : 0.f) + v;
-                }
-            }
-        }
-    }
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -299,19 +229,6 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
                         : co_carve(lds_raw, a.np, ldc, H, false);
     const float cb = a.cbias[0];
 
-    // ---- the pair's projections: Q2 = X2 . WbT, Z1 = X1 . ZW1T + zb, Z2 = X2 . ZW2T + zb (kept for the backward) ----
-    if (a.WbT != nullptr) {
-        // (Z's J columns -- j_layer(atoms), o of the ZC -- are no longer formed per atom: see the pooled outputs below)
-        CoProj pz1{{a.X1, nullptr}, {d, 0}, {d, 0}, {a.ZW1T + o, nullptr}, {ZC, 0}, 1, a.Z1w + o, ZC, ZC - o, a.zb1 + o, r1, n1, 0};
-        CoProj pq2{{a.X2, nullptr}, {d, 0}, {d, 0}, {a.WbT, nullptr}, {d, 0}, 1, a.Q2w, d, d, nullptr, r2, n2, 0};
-        CoProj pz2{{a.X2, nullptr}, {d, 0}, {d, 0}, {a.ZW2T + o, nullptr}, {ZC, 0}, 1, a.Z2w + o, ZC, ZC - o, a.zb2 + o, r2, n2, 0};
-        const int f1 = co_proj_blocks(pz1), f2 = f1 + co_proj_blocks(pq2);
-        co_project<NW>(pz1, 0, wave, lane);
-        co_project<NW>(pq2, f1, wave, lane);
-        co_project<NW>(pz2, f2, wave, lane);
-        __syncthreads();            // the workgroup's own global writes are visible to all of its waves from here on
-    }
-
     for (int idx = tid; idx < n1 * H; idx += NT) L.P1s[idx] = a.Z1[(size_t)(r1 + idx / H) * ZC + o + idx % H];
     for (int idx = tid; idx < n2 * H; idx += NT) L.P2s[idx] = a.Z2[(size_t)(r2 + idx / H) * ZC + o + idx % H];
     if constexpr (BIG) {
@@ -454,64 +371,35 @@ __global__ __launch_bounds__(NT) void k_coattn_fwd(CoArgs a) {
     __syncthreads();
 
     // ---- pooled outputs: compact_k = sum_atoms w * alpha * j_layer(atoms)  (:368-369) ----
-    // j_layer is affine, so the sum is taken BEFORE the layer: compact_k = (sum_atoms w alpha X) . Wj^T + (sum w alpha) b_j --
-    // one d x o matrix-vector product per molecule instead of an n x d x o projection per molecule (o of Z's ZC columns:
-    // 128 of 144 at C2, i.e. 62 % of the co-attention's projection flops, forward, backward and weight gradient alike).
-    // thread (k group, side, column): the NT / 256 groups split the atoms (the q range in the product), partial sums meet
-    // in LDS in a fixed order (C is dead by now)
+    // thread (k group, side, column): the NT / 256 groups split the atoms, partial sums meet in LDS (C is dead by now)
     {
         constexpr int KG = NT / 256;
         const int kg = tid >> 8, side = (tid >> 7) & 1, t = tid & 127;
-        const float* X = side == 0 ? a.X1 + (size_t)r1 * d : a.X2 + (size_t)r2 * d;
-        const float* WT = side == 0 ? a.ZW1T : a.ZW2T;
-        const float* zb = side == 0 ? a.zb1 : a.zb2;
+        const float* Z = side == 0 ? a.Z1 + (size_t)r1 * ZC : a.Z2 + (size_t)r2 * ZC;
         const float* al = side == 0 ? L.s1 : L.s2;
         const float* ww = side == 0 ? L.w1s : L.w2s;
         const int n = side == 0 ? n1 : n2;
         const int chunk = (n + KG - 1) / KG, k_lo = kg * chunk, k_hi = (k_lo + chunk) < n ? (k_lo + chunk) : n;
         float* out = (side == 0 ? a.out1 : a.out2) + (size_t)b * o;
-        float* part = L.Cs;                     // [KG][2][128]
-        float* pxs = L.Cs + KG * 256;           // [2][128]: the current 128-column chunk of sum_k w alpha X[k, :]
-        float sal = 0.f;
-        for (int k = 0; k < n; ++k) sal += ww[k] * al[k];
+        float* part = L.Cs;                     // [KG][2][128] per pass over the columns
         for (int c0 = 0; c0 < o; c0 += 128) {
             const int c = c0 + t;
-            float oacc = 0.f;
-            for (int q0 = 0; q0 < d; q0 += 128) {
-                const int q = q0 + t;
-                float acc = 0.f;
-                if (q < d) {
+            float acc = 0.f;
+            if (c < o) {
 #pragma unroll 8
-                    for (int k = k_lo; k < k_hi; ++k) acc += (ww[k] * al[k]) * X[(size_t)k * d + q];
-                }
-                __syncthreads();
-                part[(kg * 2 + side) * 128 + t] = acc;
-                __syncthreads();
-                if (kg == 0) {
-                    float v = part[side * 128 + t];
-#pragma unroll
-                    for (int g = 1; g < KG; ++g) v += part[(g * 2 + side) * 128 + t];
-                    pxs[side * 128 + t] = v;
-                }
-                __syncthreads();
-                if (c < o) {
-                    const int qn = (d - q0) < 128 ? (d - q0) : 128;
-                    const int qc = (qn + KG - 1) / KG, qa = kg * qc, qb = (qa + qc) < qn ? (qa + qc) : qn;
-#pragma unroll 8
-                    for (int qq = qa; qq < qb; ++qq) oacc += pxs[side * 128 + qq] * WT[(size_t)(q0 + qq) * ZC + c];
-                }
+                for (int k = k_lo; k < k_hi; ++k) acc += ww[k] * al[k] * Z[(size_t)k * ZC + c];
             }
             if (KG == 1) {
-                if (c < o) out[c] = oacc + sal * zb[c];
+                if (c < o) out[c] = acc;
             } else {
                 __syncthreads();
-                part[(kg * 2 + side) * 128 + t] = oacc;
+                part[(kg * 2 + side) * 128 + t] = acc;
                 __syncthreads();
                 if (kg == 0 && c < o) {
                     float v = part[side * 128 + t];
 #pragma unroll
                     for (int g = 1; g < KG; ++g) v += part[(g * 2 + side) * 128 + t];
-                    out[c] = v + sal * zb[c];
+                    out[c] = v;
                 }
             }
         }
@@ -543,7 +431,7 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
             for (int c = tid; c < ZC; c += NT) a.dZ1[(size_t)row * ZC + c] = 0.f;
         }
         for (int row = r2 + n2; row < a.N2 && a.rm2[row] < 0; ++row) {
-            for (int c = tid; c < d; c += NT) { a.dQ2[(size_t)row * d + c] = 0.f; if (a.Wb) a.dX2[(size_t)row * d + c] = 0.f; }
+            for (int c = tid; c < d; c += NT) a.dQ2[(size_t)row * d + c] = 0.f;
             for (int c = tid; c < ZC; c += NT) a.dZ2[(size_t)row * ZC + c] = 0.f;
         }
     }
@@ -605,62 +493,32 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
 
     __syncthreads();
 
-    // ---- pooled-output backward.  compact_s = px_s . Wj_s^T + sa_s b_j with px_s = sum_k w alpha X_k, sa_s = sum_k w alpha:
-    //      u_s = dout_s . Wj_s (one o x d product per molecule); dot[k] = d compact / d alpha_k = X_k . u_s (+ b_j . dout_s, the
-    //      same for every atom of the molecule: it cancels in the softmax backward below up to (1 - sa_s) ~ 1e-7 and is left
-    //      out); dX_k += w alpha_k u_s (added by the epilogue's projection); for the weight gradients PX = px / sa and
-    //      DJ = sa * dout, so that PX^T . DJ = px (x) dout and the column sums of DJ are db_j ----
-    {
-        float* ub = a.U + (size_t)b * 2 * d;
-        for (int idx = tid; idx < 2 * d; idx += NT) {
-            const int side = idx / d, q = idx % d;
-            const float* ZW = side == 0 ? a.ZW1 : a.ZW2;          // [ZC x d]: rows c < o are Wj
-            const float* dd = side == 0 ? L.do1 : L.do2;
-            float u = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < o; ++c) u += dd[c] * ZW[(size_t)c * d + q];
-            ub[idx] = u;
-            // px / sa for the weight gradient of Wj
-            const float* X = side == 0 ? a.X1 + (size_t)r1 * d : a.X2 + (size_t)r2 * d;
-            const float* al = side == 0 ? L.s1 : L.s2;
-            const float* ww = side == 0 ? L.w1s : L.w2s;
-            const int n = side == 0 ? n1 : n2;
-            float px = 0.f, sal = 0.f;
-#pragma unroll 4
-            for (int k = 0; k < n; ++k) { const float wa = ww[k] * al[k]; px += wa * X[(size_t)k * d + q]; sal += wa; }
-            (side == 0 ? a.PX1 : a.PX2)[(size_t)b * d + q] = px / sal;
-        }
-        for (int idx = tid; idx < 2 * o; idx += NT) {
-            const int side = idx / o, c = idx % o;
-            const float* al = side == 0 ? L.s1 : L.s2;
-            const float* ww = side == 0 ? L.w1s : L.w2s;
-            const int n = side == 0 ? n1 : n2;
-            float sal = 0.f;
-            for (int k = 0; k < n; ++k) sal += ww[k] * al[k];
-            (side == 0 ? a.DJ1 : a.DJ2)[(size_t)b * o + c] = sal * (side == 0 ? L.do1 : L.do2)[c];
-        }
-    }
-    __syncthreads();                 // u_s is visible to the whole workgroup
+    // ---- pooled-output backward: dJ = w*alpha*dout ; dot[k] = J[k,:] . dout ----
     {   // each wave takes CO_DQ rows (rbase + q NW) together: that many independent row loads in flight
         const int nrows = n1 + n2;
-        const float* ub = a.U + (size_t)b * 2 * d;
         for (int rbase = wave; rbase < nrows; rbase += CO_DQ * NW) {
             float dot[CO_DQ];
 #pragma unroll
             for (int q = 0; q < CO_DQ; ++q) dot[q] = 0.f;
-            for (int c = lane; c < d; c += 64) {
-                float xq[CO_DQ];
+            for (int c = lane; c < o; c += 64) {
+                float zq[CO_DQ];
 #pragma unroll
                 for (int q = 0; q < CO_DQ; ++q) {
                     const int row = rbase + NW * q;
                     const size_t gr = row < n1 ? (size_t)(r1 + row) : (size_t)(r2 + row - n1);
-                    xq[q] = row < nrows ? (row < n1 ? a.X1 : a.X2)[gr * d + c] : 0.f;
+                    zq[q] = row < nrows ? (row < n1 ? a.Z1 : a.Z2)[gr * ZC + c] : 0.f;
                 }
-                const float u1 = ub[c], u2 = ub[d + c];
 #pragma unroll
                 for (int q = 0; q < CO_DQ; ++q) {
                     const int row = rbase + NW * q;
-                    if (row < nrows) dot[q] += xq[q] * (row < n1 ? u1 : u2);
+                    if (row < nrows) {
+                        const bool s1 = row < n1;
+                        const int k = s1 ? row : row - n1;
+                        const float g = (s1 ? L.do1 : L.do2)[c];
+                        const float wa = s1 ? L.w1s[k] * L.s1[k] : L.w2s[k] * L.s2[k];
+                        dot[q] += zq[q] * g;
+                        (s1 ? a.dZ1 : a.dZ2)[(size_t)(s1 ? r1 + k : r2 + k) * ZC + c] = wa * g;
+                    }
                 }
             }
 #pragma unroll
@@ -937,26 +795,6 @@ __global__ __launch_bounds__(NT) void k_coattn_bwd(CoArgs a) {
             }
         }
     }
-    // ---- the projections' input gradients for the pair's own rows: dX1 += dZ1 . ZW1 ; dX2 = dQ2 . Wb + dZ2 . ZW2 ----
-    if (a.Wb != nullptr) {
-        __syncthreads();            // dQ2, dZ1, dZ2 and the energy part of dX1 of this pair are complete and visible
-        // rank-1 part: w_k alpha_k u_s (the pooled outputs' linear path); w * alpha per row into the dead dots arrays
-        if constexpr (BIG) {
-            for (int k = tid; k < n1; k += NT) L.dots1[k] = L.w1s[k] * L.s1[k];
-            for (int k = tid; k < n2; k += NT) L.dots2[k] = L.w2s[k] * L.s2[k];
-        } else {
-            if (tid < n1) L.dots1[tid] = L.w1s[tid] * L.s1[tid];
-            if (tid >= CO_MAXN && tid - CO_MAXN < n2) L.dots2[tid - CO_MAXN] = L.w2s[tid - CO_MAXN] * L.s2[tid - CO_MAXN];
-        }
-        __syncthreads();
-        const float* ub = a.U + (size_t)b * 2 * d;
-        CoProj px1{{a.dZ1 + o, nullptr}, {ZC, 0}, {ZC - o, 0}, {a.ZW1 + (size_t)o * d, nullptr}, {d, 0}, 1, a.dX1, d, d, nullptr, r1, n1, 1};
-        px1.rs = L.dots1; px1.uv = ub;
-        CoProj px2{{a.dQ2, a.dZ2 + o}, {d, ZC}, {d, ZC - o}, {a.Wb, a.ZW2 + (size_t)o * d}, {d, d}, 2, a.dX2, d, d, nullptr, r2, n2, 0};
-        px2.rs = L.dots2; px2.uv = ub + d;
-        co_project<NW>(px1, 0, wave, lane);
-        co_project<NW>(px2, co_proj_blocks(px1), wave, lane);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1011,7 +849,17 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
                 (Cbuf != nullptr) == (al2 != nullptr));
     const int ZC = bmp_coattn_zcols(o, H);
     int rc;
-    // (Q2 = X2 . WbT, Z1 = X1 . ZW1T + zb, Z2 = X2 . ZW2T + zb: inside the pair kernels since round 4 -- co_project)
+    {   // Q2 = X2 . WbT ; Z1 = X1 . ZW1T + zb ; Z2 = X2 . ZW2T + zb : three projections, one launch
+        RGArgs g[3]; memset(g, 0, sizeof(g));
+        g[0].s[0] = RGSrc{X2, nullptr, WbT, d, 0, d, d};
+        g[0].nsrc = 1; g[0].Nout = d; g[0].Y = Q2; g[0].ldy = d;
+        for (int s = 0; s < 2; ++s) {
+            g[1 + s].s[0] = RGSrc{s == 0 ? X1 : X2, nullptr, s == 0 ? ZW1T : ZW2T, d, 0, ZC, d};
+            g[1 + s].nsrc = 1; g[1 + s].Nout = ZC; g[1 + s].Y = s == 0 ? Z1 : Z2; g[1 + s].ldy = ZC; g[1 + s].bias = zb + ((mode & 2) && s ? ZC : 0);
+        }
+        const int nt[3] = {n_tiles2, n_tiles1, n_tiles2};
+        if ((rc = bmp_launch_rowgemm_multi(g, nt, 3, st))) return rc;
+    }
     const void* kf = H == 8 ? (const void*)k_coattn_fwd<8, CO_NT_FWD> : H == 4 ? (const void*)k_coattn_fwd<4, CO_NT_FWD>
                                                                               : (const void*)k_coattn_fwd<0, CO_NT_FWD>;
     if ((rc = co_set_lds(kf, 160 * 1024))) return rc;
@@ -1020,7 +868,6 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2; a.coff = coff; a.wa1 = wa1; a.wa2 = wa2; a.cbias = cbias;
     a.d = d; a.o = o; a.H = H; a.act = act; a.mode = mode & 1; a.order = order;
     a.Cbuf = Cbuf; a.H1 = H1; a.H2 = H2; a.al1 = al1; a.al2 = al2; a.out1 = out1; a.out2 = out2;
-    a.WbT = WbT; a.ZW1T = ZW1T; a.ZW2T = ZW2T; a.zb1 = zb; a.zb2 = zb + ((mode & 2) ? ZC : 0); a.Q2w = Q2; a.Z1w = Z1; a.Z2w = Z2;
     // one launch per size class: LDS (and so the workgroups per CU) follows the pairs' actual sizes.  (The callers hand
     // the forward ONE class sized by the largest pair: its own class for a handful of big pairs, beside the others on a
     // second stream as the backward does below, measured 0.5 % slower on the C2 / C3 steps.)
@@ -1052,12 +899,6 @@ extern "C" int bmp_coattn_nie_fwd(const float* X1, int n_tiles1, const float* X2
     return 0;
 }
 
-static size_t co_al16(size_t n) { return (n + 15) & ~(size_t)15; }
-static int co_bp(int B) { return (B + 31) & ~31; }      // PX / DJ are GEMM operands: rows padded to 32 (the pad rows are zero)
-static size_t co_mol_ws_floats(int B, int d, int o) {
-    return co_al16((size_t)B * 2 * d) + 2 * co_al16((size_t)co_bp(B) * d) + 2 * co_al16((size_t)co_bp(B) * o);
-}
-
 extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d, int o, int H, int B, int nbig, int np_big) {
     const int ZC = bmp_coattn_zcols(o, H);
     const int N1 = n_tiles1 * BMP_R, N2 = n_tiles2 * BMP_R;
@@ -1071,24 +912,13 @@ extern "C" size_t bmp_coattn_nie_bwd_ws_floats(int n_tiles1, int n_tiles2, int d
     if (s4 > slab) slab = s4;
     {
         const WGArgs g[3] = {WGArgs{nullptr, nullptr, d, 0, nullptr, d, d, d, N2, nullptr, d, 0, nullptr, 0, nullptr},
-                             WGArgs{nullptr, nullptr, d, 0, nullptr, ZC, d, ZC - o, N1, nullptr, ZC, 0, (float*)16, 0, nullptr},
-                             WGArgs{nullptr, nullptr, d, 0, nullptr, ZC, d, ZC - o, N2, nullptr, ZC, 0, (float*)16, 1, nullptr}};
+                             WGArgs{nullptr, nullptr, d, 0, nullptr, ZC, d, ZC, N1, nullptr, ZC, 0, (float*)16, 0, nullptr},
+                             WGArgs{nullptr, nullptr, d, 0, nullptr, ZC, d, ZC, N2, nullptr, ZC, 0, (float*)16, 1, nullptr}};
         const size_t s5 = bmp_wgrad_multi_ws_floats(g, 3);
         if (s5 > slab) slab = s5;
-        const int Bp = co_bp(B);
-        const WGArgs gj[3] = {WGArgs{nullptr, nullptr, d, 0, nullptr, d, d, d, N2, nullptr, d, 0, nullptr, 0, nullptr},
-                              WGArgs{nullptr, nullptr, d, 0, nullptr, o, d, o, Bp, nullptr, ZC, 0, (float*)16, 0, nullptr},
-                              WGArgs{nullptr, nullptr, d, 0, nullptr, o, d, o, Bp, nullptr, ZC, 0, (float*)16, 1, nullptr}};
-        const size_t s6 = bmp_wgrad_multi_ws_floats(gj, 3);
-        if (s6 > slab) slab = s6;
-        const size_t s7 = bmp_wgrad_ws_floats(Bp, d, o), s8 = bmp_wgrad_ws_floats(Nm, d, ZC - o), s9 = bmp_colsum_ws_floats(Nm, ZC - o);
-        if (s7 > slab) slab = s7;
-        if (s8 > slab) slab = s8;
-        if (s9 > slab) slab = s9;
     }
-    // ... | U [B x 2d] | PX1, PX2 [B x d] | DJ1, DJ2 [B x o]  (the pooled outputs' per-molecule path)
-    return (size_t)N2 * d + (size_t)(N1 + N2) * ZC + (size_t)B * (2 * H + 1) + slab + 16 + bmp_coattn_big_ws_floats(np_big, H, o, nbig, 1) +
-           co_mol_ws_floats(B, d, o);
+    // dQ2 [N2 x d] | dZ1 [N1 x ZC] | dZ2 [N2 x ZC] | dpart [B x (2H+1)] | slab | the oversized class's images
+    return (size_t)N2 * d + (size_t)(N1 + N2) * ZC + (size_t)B * (2 * H + 1) + slab + 16 + bmp_coattn_big_ws_floats(np_big, H, o, nbig, 1);
 }
 
 // Backward.  Wb [d x d] = W natural ([p][q]) (dX2 += dQ2 . W); ZW1/ZW2 [ZC x d] = transposes of ZW*T.
@@ -1114,21 +944,8 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     float* dZ1 = dQ2 + (size_t)N2 * d;
     float* dZ2 = dZ1 + (size_t)N1 * ZC;
     float* dpart = dZ2 + (size_t)N2 * ZC;
-    float* slab0 = dpart + (size_t)B * (2 * H + 1);
-    slab0 = ws + co_al16((size_t)(slab0 - ws));
-    float* Uw = slab0;
-    const int Bp = co_bp(B);
-    float* PX1 = Uw + co_al16((size_t)B * 2 * d), *PX2 = PX1 + co_al16((size_t)Bp * d);
-    float* DJ1 = PX2 + co_al16((size_t)Bp * d), *DJ2 = DJ1 + co_al16((size_t)Bp * o);
-    float* slab = DJ2 + co_al16((size_t)Bp * o);
+    float* slab = dpart + (size_t)B * (2 * H + 1);
     hipError_t e;
-    if (Bp > B) {       // the pad rows of the per-molecule GEMM operands
-        float* pads[4] = {PX1, PX2, DJ1, DJ2};
-        for (int i = 0; i < 4; ++i) {
-            const int w_ = i < 2 ? d : o;
-            if ((e = hipMemsetAsync(pads[i] + (size_t)B * w_, 0, (size_t)(Bp - B) * w_ * sizeof(float), st)) != hipSuccess) return (int)e;
-        }
-    }
     // rows outside every pair (dead rows) must read as zero in the GEMMs below: the pair kernels write every row of every
     // molecule (its dZ padding columns included) and, with the row -> molecule maps of the packed batches (-1: no molecule),
     // the dead rows behind a tile's last molecule; without the maps everything is cleared first (125 MB of fills at C2)
@@ -1146,11 +963,6 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     a.dout1 = dout1; a.dout2 = dout2; a.dQ2 = dQ2; a.dX1 = dX1; a.dZ1 = dZ1; a.dZ2 = dZ2; a.dpart = dpart;
     if (row_mol1 && row_mol2) { a.rm1 = row_mol1; a.rm2 = row_mol2; a.N1 = N1; a.N2 = N2; }
     a.gscale = gscale;
-    a.Wb = Wb; a.ZW1 = ZW1; a.ZW2 = ZW2; a.dX2 = dX2;
-    a.U = Uw; a.PX1 = PX1; a.PX2 = PX2; a.DJ1 = DJ1; a.DJ2 = DJ2;
-    if (!(row_mol1 && row_mol2)) {      // without the maps the pair kernels do not know the dead rows: cleared here
-        if ((e = hipMemsetAsync(dX2, 0, (size_t)N2 * d * sizeof(float), st)) != hipSuccess) return (int)e;
-    }
     if (!st_w) st_w = st;
     {
         const int cnt[4] = {n32, n64, n96, n128};
@@ -1196,26 +1008,27 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
         if (beside && (rc = bmp_stream_after(st_w, st))) return rc;
     }
     if ((rc = bmp_fork_to(st, st_w))) return rc;        // dQ2, dZ1, dZ2, dpart are complete: the weight gradients may start
-    // (dX1 += dZ1 . ZW1, dX2 = dQ2 . W + dZ2 . ZW2: inside the pair kernels since round 4 -- co_project)
-    {   // the weight gradients: a few tiles each.  dWbT = X2^T dQ2; the P | v columns of dZW_kT = X_k^T dZ_k[:, o:] with their
-        // column sums as dzb[o:]; the J columns per MOLECULE: dZW_kT[:, :o] = PX_k^T DJ_k over the B pairs, column sums of
-        // DJ_k = dzb[:o] (the second side accumulates into the first's sums unless the sides have a bias row each)
-        const int two = (mode & 2) ? 1 : 0;
+    {   // dX1 += dZ1 . ZW1 (K = ZC) ; dX2 = dQ2 . W + dZ2 . ZW2 : one launch
+        RGArgs g[2]; memset(g, 0, sizeof(g));
+        g[0].s[0] = RGSrc{dZ1, nullptr, ZW1, ZC, 0, d, ZC};
+        g[0].nsrc = 1; g[0].Nout = d; g[0].Y = dX1; g[0].ldy = d; g[0].accumulate = 1;
+        g[1].s[0] = RGSrc{dQ2, nullptr, Wb, d, 0, d, d};
+        g[1].s[1] = RGSrc{dZ2, nullptr, ZW2, ZC, 0, d, ZC};
+        g[1].nsrc = 2; g[1].Nout = d; g[1].Y = dX2; g[1].ldy = d;
+        const int nt[2] = {n_tiles1, n_tiles2};
+        if ((rc = bmp_launch_rowgemm_multi(g, nt, 2, st))) return rc;
+    }
+    {   // the three weight gradients: a few tiles each, one launch.  dzb = column sums of dZ1 and dZ2: they ride along
+        // with the two GEMMs that read those arrays anyway (the second reduction accumulates into the first's result)
         const WGArgs g[3] = {WGArgs{X2, nullptr, d, 0, dQ2, d, d, d, N2, dWbT, d, 0, nullptr, 0, nullptr},
-                             WGArgs{X1, nullptr, d, 0, dZ1 + o, ZC, d, ZC - o, N1, dZW1T + o, ZC, 0, dzb + o, 0, nullptr},
-                             WGArgs{X2, nullptr, d, 0, dZ2 + o, ZC, d, ZC - o, N2, dZW2T + o, ZC, 0, dzb + o + (two ? ZC : 0), two ? 0 : 1, nullptr}};
-        const WGArgs gj[2] = {WGArgs{PX1, nullptr, d, 0, DJ1, o, d, o, Bp, dZW1T, ZC, 0, dzb, 0, nullptr},
-                              WGArgs{PX2, nullptr, d, 0, DJ2, o, d, o, Bp, dZW2T, ZC, 0, dzb + (two ? ZC : 0), two ? 0 : 1, nullptr}};
-        if (d <= 128 && d >= 64 && o >= 64) {       // the three problems with full-width outputs: one launch
-            const WGArgs gm[3] = {g[0], gj[0], gj[1]};
-            if ((rc = bmp_launch_wgrad_multi(gm, 3, slab, st_w))) return rc;
+                             WGArgs{X1, nullptr, d, 0, dZ1, ZC, d, ZC, N1, dZW1T, ZC, 0, dzb, 0, nullptr},
+                             WGArgs{X2, nullptr, d, 0, dZ2, ZC, d, ZC, N2, dZW2T, ZC, 0, dzb + ((mode & 2) ? ZC : 0), (mode & 2) ? 0 : 1, nullptr}};
+        if (d <= 128 && d >= 64 && ZC >= 64) {
+            if ((rc = bmp_launch_wgrad_multi(g, 3, slab, st_w))) return rc;
         } else {
-            if ((rc = bmp_launch_wgrad(g[0], slab, st_w))) return rc;
-            for (int p = 0; p < 2; ++p)
-                if ((rc = bmp_launch_wgrad(gj[p], slab, st_w))) return rc;
+            for (int p = 0; p < 3; ++p)
+                if ((rc = bmp_launch_wgrad(g[p], slab, st_w))) return rc;
         }
-        for (int p = 1; p < 3; ++p)                  // the narrow ones (H + 1 columns, padded)
-            if ((rc = bmp_launch_wgrad(g[p], slab, st_w))) return rc;
     }
     return bmp_launch_colsum(dpart, 2 * H + 1, B, 2 * H + 1, dwa, 0, slab, st_w);
 }
