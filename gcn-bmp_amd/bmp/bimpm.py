@@ -28,8 +28,8 @@ class BiMPMFn(Function):
         X1, X2 = X1.contiguous(), X2.contiguous()
         P, Q, R = P.contiguous(), Q.contiguous(), R.contiguous()
         d, H, B = X1.shape[1], P.shape[0], meta["B"]
-        if not L.bmp_bimpm_supported(d, H, maxn):
-            raise ValueError(f"BiMPM: molecules of {maxn} rows x {d} features do not fit the pair kernel's LDS staging")
+        if not L.bmp_bimpm_supported(d, H, maxn):          # (any molecule size since round 4: big pairs stage their rows in the workspace)
+            raise ValueError(f"BiMPM: unsupported shape (d = {d}, head = {H}, {maxn} rows)")
         out1 = torch.empty(B, 3 * H, dtype=torch.float32, device=X1.device)
         out2 = torch.empty_like(out1)
         nws = L.bmp_bimpm_ws_floats(d, H, maxn, B, 0)

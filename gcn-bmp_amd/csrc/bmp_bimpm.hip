@@ -35,6 +35,10 @@ struct BmArgs {
     const float* dout1; const float* dout2;
     float* dX1; float* dX2;                             // [N x d], every row of every pair written
     float* wslab;                                       // [grid x 3 x H x d] per-workgroup weight-gradient sums
+    // the global-memory class (round 4): a pair whose two molecules' rows do not fit 160 KB of LDS (more than ~150 rows at
+    // d = 128; the reference has no size limit, bimpm.py:17-199 / train_ddi_modify.py:256) stages them in the workgroup's
+    // scratch slice instead -- same program, same order of operations
+    int stage_global; size_t stage_off;                 // floats into the workgroup's scratch slice
 };
 
 // per-pair scratch carve-up (float slots; int arrays share the slots)
@@ -210,8 +214,8 @@ __global__ __launch_bounds__(BM_NT) void k_bimpm(BmArgs a) {
         __syncthreads();
         const int r1 = a.r1[pr], n1 = a.n1[pr], r2 = a.r2[pr], n2 = a.n2[pr];
         // ---- stage both molecules' rows (LDS, odd row stride) and their multiplicities ----
-        float* Xs = lds;
-        float* Ys = lds + (size_t)n1 * LDX;
+        float* Xs = a.stage_global ? a.scratch + (size_t)blockIdx.x * a.scratch_per_wg + a.stage_off : lds;
+        float* Ys = Xs + (size_t)n1 * LDX;
         float* wx = Ys + (size_t)n2 * LDX;
         float* wy = wx + n1;
         for (int idx = tid; idx < n1 * d; idx += BM_NT) Xs[(idx / d) * LDX + idx % d] = a.X1[(size_t)(r1 + idx / d) * d + idx % d];
@@ -434,12 +438,14 @@ static int bm_grid(int B) { return B < 512 ? B : 512; }
 
 static size_t bm_lds_bytes(int maxn, int d) { return ((size_t)2 * maxn * (d + 1) + 2 * maxn + 16) * sizeof(float); }
 
-extern "C" int bmp_bimpm_supported(int d, int H, int maxn) {
-    return d > 0 && H > 0 && maxn > 0 && bm_lds_bytes(maxn, d) <= 160 * 1024;
-}
+static bool bm_in_lds(int maxn, int d) { return bm_lds_bytes(maxn, d) <= 160 * 1024; }
+static size_t bm_stage_floats(int maxn, int d) { return bm_in_lds(maxn, d) ? 0 : (bm_lds_bytes(maxn, d) / sizeof(float) + 15) & ~(size_t)15; }
+
+// Any molecule size: pairs that fit stage their rows in LDS, larger ones in the workspace (bmp_bimpm_ws_floats grows).
+extern "C" int bmp_bimpm_supported(int d, int H, int maxn) { return d > 0 && H > 0 && maxn > 0; }
 
 extern "C" size_t bmp_bimpm_ws_floats(int d, int H, int maxn, int B, int backward) {
-    return (size_t)bm_grid(B) * (bm_scratch_floats(maxn, d, H, backward != 0) + (backward ? (size_t)3 * H * d : 0));
+    return (size_t)bm_grid(B) * (bm_scratch_floats(maxn, d, H, backward != 0) + bm_stage_floats(maxn, d) + (backward ? (size_t)3 * H * d : 0));
 }
 
 static int bm_fill(BmArgs& a, const float* X1, const float* X2, int d, int H, const float* w1, const int* r1, const int* n1,
@@ -450,7 +456,8 @@ static int bm_fill(BmArgs& a, const float* X1, const float* X2, int d, int H, co
     BMP_REQUIRE(bmp_bimpm_supported(d, H, maxn));
     a.X1 = X1; a.X2 = X2; a.d = d; a.H = H; a.B = B; a.w1 = w1; a.w2 = w2; a.r1 = r1; a.n1 = n1; a.r2 = r2; a.n2 = n2;
     a.P = P; a.Q = Q; a.R = R; a.maxn = maxn;
-    a.scratch = ws; a.scratch_per_wg = bm_scratch_floats(maxn, d, H, bwd);
+    a.scratch = ws; a.scratch_per_wg = bm_scratch_floats(maxn, d, H, bwd) + bm_stage_floats(maxn, d);
+    a.stage_global = bm_in_lds(maxn, d) ? 0 : 1; a.stage_off = bm_scratch_floats(maxn, d, H, bwd);
     return 0;
 }
 
@@ -466,7 +473,7 @@ extern "C" int bmp_bimpm_fwd(const float* X1, const float* X2, int d, int H, con
     BMP_REQUIRE(out1 && out2 && ws_floats >= bmp_bimpm_ws_floats(d, H, maxn, B, 0));
     a.out1 = out1; a.out2 = out2;
     if (int rc_attr = bmp_lds_attr((const void*)k_bimpm<false>, (size_t)(160 * 1024))) return rc_attr;
-    hipLaunchKernelGGL((k_bimpm<false>), dim3(bm_grid(B)), dim3(BM_NT), bm_lds_bytes(maxn, d), st, a);
+    hipLaunchKernelGGL((k_bimpm<false>), dim3(bm_grid(B)), dim3(BM_NT), a.stage_global ? 64 : bm_lds_bytes(maxn, d), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
 }
@@ -485,7 +492,7 @@ extern "C" int bmp_bimpm_bwd(const float* dout1, const float* dout2, const float
     const int grid = bm_grid(B);
     a.wslab = ws + (size_t)grid * a.scratch_per_wg;
     if (int rc_attr = bmp_lds_attr((const void*)k_bimpm<true>, (size_t)(160 * 1024))) return rc_attr;
-    hipLaunchKernelGGL((k_bimpm<true>), dim3(grid), dim3(BM_NT), bm_lds_bytes(maxn, d), st, a);
+    hipLaunchKernelGGL((k_bimpm<true>), dim3(grid), dim3(BM_NT), a.stage_global ? 64 : bm_lds_bytes(maxn, d), st, a);
     BMP_LAUNCH_CHECK();
     const int n = 3 * H * d;
     hipLaunchKernelGGL(k_bimpm_reduce, dim3((n + 255) / 256), dim3(256), 0, st, a.wslab, grid, n, dP, dQ, dR, H * d);

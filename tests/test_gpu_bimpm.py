@@ -12,7 +12,10 @@ T = torch.from_numpy
 from parity_util import close as _close      # asserts AND logs the achieved relative error
 
 
-@pytest.mark.parametrize("d,H,mb,N1,N2", [(32, 8, 5, 9, 13), (64, 16, 3, 33, 20), (128, 128, 2, 12, 7)])
+@pytest.mark.parametrize("d,H,mb,N1,N2", [(32, 8, 5, 9, 13), (64, 16, 3, 33, 20), (128, 128, 2, 12, 7),
+                                          # molecules beyond the 160 KB of LDS two staged molecules may take (~150 rows at d = 128): the
+                                          # global-memory class of k_bimpm (round 4; bimpm.py:17-199 has no size limit)
+                                          (128, 16, 2, 200, 150), (128, 8, 2, 300, 40), (64, 16, 1, 330, 310)])
 def test_bimpm_dense_arrays_match_oracle(d, H, mb, N1, N2):
     from bmp.bimpm import BiMPM
     from oracle import ref_cpu as O
@@ -32,9 +35,46 @@ def test_bimpm_dense_arrays_match_oracle(d, H, mb, N1, N2):
     assert m1.shape == (mb, 3 * H)
     ((m1 * wv1.float().to(dev)).sum() + (m2 * wv2.float().to(dev)).sum()).backward()
     _close(m1, m1o, "mol_1"); _close(m2, m2o, "mol_2")
-    _close(x1.grad, a1.grad, "d atoms_1"); _close(x2.grad, a2.grad, "d atoms_2")
+    # hundreds of atoms per molecule: thousands of max selections per pair, and a float32 near-tie that picks the other atom
+    # than float64 moves a gradient by the difference of the two candidates (the float32 ORACLE differs from its float64 form
+    # by 1.3e-3 on such inputs); the values above stay at 1e-4.  Stated tolerance for those cases: 2e-3.
+    # (that the global-memory class is the SAME program is pinned bit for bit below, where no tie can hide anything)
+    gtol = 2e-3 if max(N1, N2) >= 150 else 1e-4
+    _close(x1.grad, a1.grad, "d atoms_1", tol=gtol); _close(x2.grad, a2.grad, "d atoms_2", tol=gtol)
     for n in ("max_pooling_W", "att_mean_W", "att_max_W"):
-        _close(getattr(mod, n).grad, p[f"attn/{n}"].grad, f"d {n}")
+        _close(getattr(mod, n).grad, p[f"attn/{n}"].grad, f"d {n}", tol=gtol)
+
+
+def test_bimpm_global_memory_class_is_the_lds_program_bit_for_bit():
+    """`maxn` is an upper bound of the pairs' molecule sizes: overstated (400 rows at d = 128 do not fit 160 KB of LDS), the SAME
+    small pairs run through the global-memory staging of k_bimpm; outputs and every gradient must equal the LDS-staged call
+    exactly."""
+    from bmp import packed, synth
+    from bmp.bimpm import BiMPMFn
+    from bmp.coattention import pair_rows
+    from bmp.ggnn import PackedAtoms
+    dev = torch.device("cuda:0")
+    store = synth.make_store(20, seed=3, n_lo=3, n_hi=40, n_mean=14)
+    ms = packed.MolStore(store)
+    rs = np.random.RandomState(2)
+    i1, i2 = rs.randint(0, 20, 11), rs.randint(0, 20, 11)
+    pb = packed.pack_from_store(ms, [i1, i2], device=dev)
+    d, H = 128, 16
+    g = torch.Generator().manual_seed(1)
+    rows = torch.randn(pb.n_rows, d, generator=g).to(dev)
+    W = [(torch.randn(H, d, generator=g) * 0.1).to(dev) for _ in range(3)]
+    c1, c2 = torch.randn(11, 3 * H, generator=g).to(dev), torch.randn(11, 3 * H, generator=g).to(dev)
+    res = []
+    for maxn in (pb.max_rows_per_mol, 400):
+        x = rows.clone().requires_grad_()
+        Ws = [w.clone().requires_grad_() for w in W]
+        at = PackedAtoms(x, pb, None)
+        X1, X2, w1, w2, meta, _ = pair_rows(at, at)
+        o1, o2 = BiMPMFn.apply(X1, X2, Ws[0], Ws[1], Ws[2], w1, w2, meta, maxn)
+        ((o1 * c1).sum() + (o2 * c2).sum()).backward()
+        res.append((o1.detach(), o2.detach(), x.grad, Ws[0].grad, Ws[1].grad, Ws[2].grad))
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_)
 
 
 @pytest.mark.parametrize("form", ["two-sided", "four arrays"])
