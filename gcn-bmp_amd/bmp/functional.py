@@ -199,6 +199,19 @@ class GRUStateFn(Function):
         return dhd, dm, ds, dWT, dUrzT, dUcT, db, None
 
 
+# The step's weight-gradient launches walk the rows that have a bond of the type only (PackedMolBatch.type_rows_T; DESIGN.md
+# section 3a round 4).  BMP_WGRAD_LISTS=0: every row, as before (A/B switch of bench.py and the tests).
+_WGRAD_LISTS = os.environ.get("BMP_WGRAD_LISTS", "1") != "0"
+
+
+def type_rows(pb):
+    """(idx, cnt) pointers' tensors of the batch's transposed CSR, or (None, None)."""
+    if not _WGRAD_LISTS:
+        return None, None
+    tr = pb.type_rows_T()
+    return tr if tr is not None else (None, None)
+
+
 def step_supported(d: int) -> bool:
     return bool(_lib.lib().bmp_ggnn_step_supported(int(d)))
 
@@ -279,8 +292,9 @@ class GGNNStepFn(Function):
         acc = 1 if (st is not None and st["seen"] > 0) else 0
         nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
         ws = _ws(nws, dev)
+        tri, trc = type_rows(pb)
         check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(o1), ptr(o2), ptr(dUcT), ptr(cs),
-                                    acc, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+                                    acc, ptr(tri), ptr(trc), ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
         if st is not None:
             st["seen"] += 1
             if st["seen"] < cache[("n",) + grp[1:]]:
@@ -614,6 +628,8 @@ class PStepFn(Function):
                                       ptr(c), ptr(hout), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, st), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
+        if m is not None:
+            type_rows(pb)               # (built once per batch, here on the chain's stream: the backward's side stream finds them)
         _register(state, gkey)
         return hout
 
@@ -631,11 +647,13 @@ class PStepFn(Function):
                                   ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()), "bmp_ggnn_step_bwd")
         acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
 
+        tri, trc = type_rows(pb)
+
         def wgrad(st, ws_of):
             nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
             ws = ws_of(nws, h.device)
             check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(G["o1"]), ptr(G["o2"]),
-                                        ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
+                                        ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(tri), ptr(trc), ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
 
         _on_side(ctx.state, (h, m, rz, gda), wgrad)
         return dh, None, None, None, None, None, None, None
@@ -685,6 +703,8 @@ class PTStepsFn(Function):
                                        ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, st), "bmp_ggnn_steps_fwd")
         ctx.save_for_backward(h, *flat)
         ctx.pb, ctx.steps, ctx.state, ctx.T, ctx.keep = pb, steps, state, T, keep
+        if keep:
+            type_rows(pb)               # (once per batch, on the chain's stream)
         for s_ in steps:
             _register(state, s_[2])
         return hout[-1]
@@ -700,6 +720,7 @@ class PTStepsFn(Function):
         bufs = [sv[1 + 4 * t: 5 + 4 * t] for t in range(T)]
         N, d = h0.shape
         dh = dhout.contiguous()
+        tri, trc = type_rows(pb)
         for t in range(T - 1, -1, -1):
             W, G, gkey, first = steps[t]
             m, rz, c, _hout = bufs[t]
@@ -715,7 +736,7 @@ class PTStepsFn(Function):
                 nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
                 ws = ws_of(nws, h0.device)
                 check(L.bmp_ggnn_step_wgrad(ptr(h_in), ptr(m), ptr(rz), ptr(gda), N, d, int(first), ptr(G["o1"]), ptr(G["o2"]),
-                                            ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
+                                            ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(tri), ptr(trc), ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
 
             _on_side(ctx.state, (h_in, m, rz, gda), wgrad)
             dh = dprev
@@ -824,6 +845,8 @@ class PGRUFn(Function):
                                 _at(c, r0), _at(hout, r0), st), "bmp_gru_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
+        if m is not None:
+            type_rows(pb)               # (built once per batch, here on the chain's stream: the backward's side stream finds them)
         _register(state, gkey)
         return hout
 
@@ -904,6 +927,8 @@ def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None, bufs=None):
     L = _lib.lib()
     N, d = x.shape
     out, wdeg = bufs if bufs is not None else rel_buffers(N, d, x.device)
+    if wdeg is not None:
+        type_rows(pb)                   # (once per batch, on the chain's stream: the backward's weight-gradient launches walk them)
     for t0, nt, st in _fwd_parts(state, pb, (x, out, wdeg)):
         check(L.bmp_relgcn_layer_fwd(ptr(x), t0, nt, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
                                      ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, st),
@@ -920,11 +945,13 @@ def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate,
                                  ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()),
               "bmp_relgcn_layer_bwd")
 
+    tri, trc = type_rows(pb)
+
     def wgrad(st, ws_of):
         nws = L.bmp_relgcn_layer_wgrad_ws_floats(N, d)
         ws = ws_of(nws, x.device)
-        check(L.bmp_relgcn_layer_wgrad(ptr(x), ptr(wdeg), ptr(gda), N, d, ptr(o1), ptr(dbE), ptr(cs), int(accumulate), ptr(ws),
-                                       nws, st), "bmp_relgcn_layer_wgrad")
+        check(L.bmp_relgcn_layer_wgrad(ptr(x), ptr(wdeg), ptr(gda), N, d, ptr(o1), ptr(dbE), ptr(cs), int(accumulate), ptr(tri), ptr(trc),
+                                       ptr(ws), nws, st), "bmp_relgcn_layer_wgrad")
 
     _on_side(state, (x, wdeg, gda), wgrad)
     return dx

@@ -176,6 +176,27 @@ class PackedMolBatch:
         if lo < 0 or hi >= n_atom_types:
             raise ValueError(f"atom ids must lie in [0, {n_atom_types}); this batch has ids in [{lo}, {hi}]")
 
+    def type_rows_T(self):
+        """(idx [4 x N] int32, cnt [4] int32), device tensors: the rows of the TRANSPOSED CSR that hold an entry of bond type e
+        (``bmp_type_rows``) -- the rows whose gathered gradient G_e is not zero, which is all the step's weight-gradient
+        launches need to walk (73 / 19 / 2 / 52 % of a DDI batch's rows).  Built once per batch on the caller's stream (two small
+        launches) and kept; host batches: None."""
+        if not self.atom_id.is_cuda:
+            return None
+        tr = self._cache.get("type_rows_T")
+        if tr is None:
+            from . import _lib
+            from ._lib import check, ptr, stream
+            L = _lib.lib()
+            N, dev = self.n_rows, self.atom_id.device
+            idx = torch.empty(4 * N, dtype=torch.int32, device=dev)
+            cnt = torch.empty(4, dtype=torch.int32, device=dev)
+            ws = torch.empty(max(int(L.bmp_type_rows_ws_ints(N)), 4), dtype=torch.int32, device=dev)
+            check(L.bmp_type_rows(ptr(self.csrT_ptr), ptr(self.csrT_col), N, ptr(idx), ptr(cnt), ptr(ws), stream()), "bmp_type_rows")
+            tr = (idx, cnt)
+            self._cache["type_rows_T"] = tr
+        return tr
+
     def with_edge_vals(self, csr_val: torch.Tensor, csrT_val: torch.Tensor) -> "PackedMolBatch":
         import dataclasses
         return dataclasses.replace(self, csr_val=csr_val, csrT_val=csrT_val, _cache={})

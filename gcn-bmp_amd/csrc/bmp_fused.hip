@@ -790,17 +790,31 @@ extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float
 //   later steps:  o1 = h^T gda [d x 7d] (+ cs) | o2 = m^T gda[:, 4d:7d] [d x 3d] | dUcT = (r*h)^T gda[:, 6d:7d] [d x d]
 //   first step (no r gate, no U term: da_r = 0 and is neither written nor read): o1 skips columns [4d, 5d), o2 skips
 //   [0, d), dUcT is zero -- 6d + 2d instead of 7d + 3d + d columns of products.
+// type_rows [4 x N] / type_cnt [4] (bmp_type_rows of the TRANSPOSED CSR; null: none): the rows whose gathered gradient G_e is
+// not zero.  With them the per-type blocks of o1 become four problems of their own that walk their lists only -- on the DDI
+// batches 1.46 N rows instead of 4 N, 8.5 instead of 11 column tiles of work for the launch -- and o1's da columns a fifth.
+static const float kTypeFrac[4] = {0.78f, 0.24f, 0.05f, 0.58f};      // expected shares (single, double, triple, aromatic): balance only
 static int step_wgrad_problems(WGArgs* g, const float* h, const float* m, const float* rz, const float* gda, int N, int d,
-                               int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate) {
-    g[0] = WGArgs{h, nullptr, d, 0, gda, 7 * d, d, first ? 6 * d : 7 * d, N, o1, 7 * d, accumulate, cs};
+                               int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate,
+                               const int* type_rows = nullptr, const int* type_cnt = nullptr) {
     g[1] = WGArgs{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, first ? 2 * d : 3 * d, N, o2, 3 * d, accumulate};
     g[2] = WGArgs{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
     if (first) {
-        g[0].skip_at = 4 * d; g[0].skip_n = d;
         g[1].skip_at = 0; g[1].skip_n = d;
         g[2].zero_only = 1;
     }
-    return 3;
+    if (type_rows == nullptr) {
+        g[0] = WGArgs{h, nullptr, d, 0, gda, 7 * d, d, first ? 6 * d : 7 * d, N, o1, 7 * d, accumulate, cs};
+        if (first) { g[0].skip_at = 4 * d; g[0].skip_n = d; }
+        return 3;
+    }
+    g[0] = WGArgs{h, nullptr, d, 0, gda + 4 * d, 7 * d, d, first ? 2 * d : 3 * d, N, o1 + 4 * d, 7 * d, accumulate, cs + 4 * d};
+    if (first) { g[0].skip_at = 0; g[0].skip_n = d; }
+    for (int e = 0; e < 4; ++e) {
+        g[3 + e] = WGArgs{h, nullptr, d, 0, gda + e * d, 7 * d, d, d, N, o1 + e * d, 7 * d, accumulate, cs + e * d};
+        g[3 + e].ridx = type_rows + (size_t)e * N; g[3 + e].rcnt = type_cnt + e; g[3 + e].rfrac = kTypeFrac[e];
+    }
+    return 7;
 }
 
 static bool step_wgrad_fusable(int N, int d) { return (d == 64 || d == 128) && (N & 31) == 0; }
@@ -809,9 +823,12 @@ extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
     size_t a = bmp_wgrad_ws_floats(N, d, 7 * d);
     if (d == 32 && (N & 7) == 0) { const size_t b = bmp_step_wgrad_small_ws_floats(N, d); if (b > a) a = b; }
     if (step_wgrad_fusable(N, d)) {
-        WGArgs g[3];
-        const int n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0);
-        const size_t b = bmp_wgrad_fused_ws_floats(g, n);
+        WGArgs g[BMP_WG_MAXP];
+        int n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0);
+        size_t b = bmp_wgrad_fused_ws_floats(g, n);
+        if (b > a) a = b;
+        n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0, (const int*)16, (const int*)16);
+        b = bmp_wgrad_fused_ws_floats(g, n);
         if (b > a) a = b;
     }
     return a;
@@ -824,9 +841,11 @@ extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
 //   cs [7d]      = column sums of gda: [dbE as e*d + c | db]
 // accumulate != 0 adds into the outputs (weight tying: one set of buffers for all steps).
 // first != 0: the da_r columns of gda are not read (bmp_ggnn_step_bwd does not write them) and count as zeros.
+// type_rows / type_cnt: optional row lists of the batch's TRANSPOSED CSR (bmp_type_rows): the per-type blocks then sum over
+// the rows that have a bond of the type only (the others' G_e rows are exact zeros: same sums, fewer products).
 extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
-                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws,
-                                   size_t ws_floats, hipStream_t st) {
+                                   int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate,
+                                   const int* type_rows, const int* type_cnt, float* ws, size_t ws_floats, hipStream_t st) {
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
     BMP_REQUIRE(h && m && rz && gda && o1 && o2 && dUcT && cs && ws);
     static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;        // A/B switch (tools, tests)
@@ -834,8 +853,10 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
         return bmp_launch_step_wgrad_small(h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate, ws, st);
     if (!unfused && step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)rz & 15) == 0 &&
         ((uintptr_t)gda & 15) == 0) {
-        WGArgs g[3];
-        const int n = step_wgrad_problems(g, h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate);
+        WGArgs g[BMP_WG_MAXP];
+        const bool lists = type_rows != nullptr && type_cnt != nullptr && bmp_wgrad_fused_lists_ok(N);
+        const int n = step_wgrad_problems(g, h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate, lists ? type_rows : nullptr,
+                                          lists ? type_cnt : nullptr);
         return bmp_launch_wgrad_fused(g, n, ws, st, BMP_KID_WGRAD_STEP);
     }
     // one launch per product (first steps: the da_r columns of gda are not written, so they are zeroed here first)
@@ -899,19 +920,33 @@ extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act
     return d == 128 ? rel_launch<128>(true, a, n_tiles, st) : rel_launch<64>(true, a, n_tiles, st);
 }
 
-static void rel_wgrad_problem(WGArgs* g, const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
-                              float* cs, int accumulate) {
-    g[0] = WGArgs{h, nullptr, d, 0, gda, 5 * d, d, 5 * d, N, o1, 5 * d, accumulate, cs};
-    g[0].wrow = wdeg; g[0].w_col0 = 4 * d; g[0].wout = dbE; g[0].ldwo = d;      // dbE = wdeg^T . dpre rides along
+static int rel_wgrad_problem(WGArgs* g, const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
+                             float* cs, int accumulate, const int* type_rows = nullptr, const int* type_cnt = nullptr) {
+    if (type_rows == nullptr) {
+        g[0] = WGArgs{h, nullptr, d, 0, gda, 5 * d, d, 5 * d, N, o1, 5 * d, accumulate, cs};
+        g[0].wrow = wdeg; g[0].w_col0 = 4 * d; g[0].wout = dbE; g[0].ldwo = d;      // dbE = wdeg^T . dpre rides along
+        return 1;
+    }
+    // the self-connection block (dpre, every row) and the four per-type blocks over their row lists (see step_wgrad_problems)
+    g[0] = WGArgs{h, nullptr, d, 0, gda + 4 * d, 5 * d, d, d, N, o1 + 4 * d, 5 * d, accumulate, cs + 4 * d};
+    g[0].wrow = wdeg; g[0].w_col0 = 0; g[0].wout = dbE; g[0].ldwo = d;
+    for (int e = 0; e < 4; ++e) {
+        g[1 + e] = WGArgs{h, nullptr, d, 0, gda + e * d, 5 * d, d, d, N, o1 + e * d, 5 * d, accumulate, cs + e * d};
+        g[1 + e].ridx = type_rows + (size_t)e * N; g[1 + e].rcnt = type_cnt + e; g[1 + e].rfrac = kTypeFrac[e];
+    }
+    return 5;
 }
 
 extern "C" size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d) {
     size_t a = bmp_wgrad_ws_floats(N, d, 5 * d), b = bmp_wgrad_ws_floats(N, 4, d);
     a = a > b ? a : b;
     if (step_wgrad_fusable(N, d)) {
-        WGArgs g[1];
-        rel_wgrad_problem(g, nullptr, (const float*)16, nullptr, N, d, nullptr, (float*)16, (float*)16, 0);
-        b = bmp_wgrad_fused_ws_floats(g, 1);
+        WGArgs g[BMP_WG_MAXP];
+        int n = rel_wgrad_problem(g, nullptr, (const float*)16, nullptr, N, d, nullptr, (float*)16, (float*)16, 0);
+        b = bmp_wgrad_fused_ws_floats(g, n);
+        if (b > a) a = b;
+        n = rel_wgrad_problem(g, nullptr, (const float*)16, nullptr, N, d, nullptr, (float*)16, (float*)16, 0, (const int*)16, (const int*)16);
+        b = bmp_wgrad_fused_ws_floats(g, n);
         if (b > a) a = b;
     }
     return a;
@@ -922,14 +957,16 @@ extern "C" size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d) {
 //   dbE [4 x d] = wdeg^T . dpre (weighted column sums of the dpre tile, carried by the same launch)
 //   cs [5d]     = column sums of gda; cs[4d:] = dbs
 extern "C" int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
-                                      float* cs, int accumulate, float* ws, size_t ws_floats, hipStream_t st) {
+                                      float* cs, int accumulate, const int* type_rows, const int* type_cnt, float* ws, size_t ws_floats,
+                                      hipStream_t st) {
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_relgcn_layer_wgrad_ws_floats(N, d));
     BMP_REQUIRE(h && wdeg && gda && o1 && dbE && cs && ws);
     static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;        // A/B switch (tools, tests)
     if (!unfused && step_wgrad_fusable(N, d) && ((uintptr_t)h & 15) == 0 && ((uintptr_t)gda & 15) == 0 && ((uintptr_t)wdeg & 15) == 0) {
-        WGArgs g[1];
-        rel_wgrad_problem(g, h, wdeg, gda, N, d, o1, dbE, cs, accumulate);
-        return bmp_launch_wgrad_fused(g, 1, ws, st, BMP_KID_WGRAD_STEP);
+        WGArgs g[BMP_WG_MAXP];
+        const bool lists = type_rows != nullptr && type_cnt != nullptr && bmp_wgrad_fused_lists_ok(N);
+        const int n = rel_wgrad_problem(g, h, wdeg, gda, N, d, o1, dbE, cs, accumulate, lists ? type_rows : nullptr, lists ? type_cnt : nullptr);
+        return bmp_launch_wgrad_fused(g, n, ws, st, BMP_KID_WGRAD_STEP);
     }
     int rc;
     WGArgs g1{h, nullptr, d, 0, gda, 5 * d, d, 5 * d, N, o1, 5 * d, accumulate, cs};

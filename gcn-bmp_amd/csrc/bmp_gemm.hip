@@ -547,6 +547,9 @@ struct WGKArgs {
     const int* onehot;      // if set, X is not read: X[row, k] = (onehot[row] == k)  (embedding gradient as a GEMM)
     int skip_at = 0x7fffffff, skip_n = 0;     // logical column j reads dY column j + (j >= skip_at ? skip_n : 0)
     const float* wrow = nullptr; int w_col0 = 0;      // weighted column sums (slab rows K + 1 .. K + 4) for columns >= w_col0
+    // row list (LDS-DMA body only): rows ridx[0 .. *rcnt), cut into nsplit parts in the kernel; zrow: >= 128 zero floats, the
+    // source of the pieces past the end of the list
+    const int* ridx = nullptr; const int* rcnt = nullptr; const float* zrow = nullptr; int nsplit = 0;
 };
 
 template <int MB, int NB>
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(WGKArgs a, int want_cs) {
 // pieces back to back), which the fragment reads -- 32 consecutive floats of a row per half-wave -- take without conflicts.
 #define WD_RS 16
 #define WD_NS 3
-template <bool HAS_X2>
+template <bool HAS_X2, bool IDX>
 __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, int bx, int by, int bz, float* sm, int ssz) {
     constexpr int XSZ = WD_RS * 128;
     constexpr int NI = WD_RS / 8;                    // DMA instructions per wave, operand and stage (a wave moves two rows each)
@@ -807,9 +810,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     const int l31 = lane & 31, hi = lane >> 5;
     const int i_tile = bx * 128, j_tile = by * 128;
     const int s = bz;
-    const int r_begin = s * a.rows_per_split;
-    const int r_end = (r_begin + a.rows_per_split) < a.N ? (r_begin + a.rows_per_split) : a.N;
-    const int nst = (r_end - r_begin) / WD_RS;
+    // IDX: the problem walks the row list ridx[0 .. count) (count is on the device): cut into nsplit parts of whole stages;
+    // the pieces of the last stage past the end of the list come from the zero row
+    const int count = IDX ? a.rcnt[0] : a.N;
+    const int rps = IDX ? ((((count + a.nsplit - 1) / a.nsplit) + WD_RS - 1) / WD_RS) * WD_RS : a.rows_per_split;
+    const int r_begin = s * rps;
+    const int r_end = (r_begin + rps) < count ? (r_begin + rps) : count;
+    const int nst = r_end > r_begin ? (r_end - r_begin + WD_RS - 1) / WD_RS : 0;
     const int c4 = tid & 31, rr = tid >> 5;          // column sums: this thread's four columns of the rows rr, rr + 8 of a stage
     const int coly = j_tile + 4 * c4;
     const bool oky = coly < a.Nn;
@@ -842,7 +849,34 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     // the counted wait below leaves the youngest NLD loads of a wave outstanding, i.e. the next stage's X / dY / X2 pieces
     const int WOFF = (HAS_X2 ? 3 : 2) * XSZ;
     const float* wsrc = do_w ? a.wrow + (size_t)(r_begin + (lane & 15)) * 4 : nullptr;
+    // IDX: the four row numbers a wave needs per stage (rows 2 w, 2 w + 1 of the stage's two 8-row halves) are wave-uniform:
+    // fetched through the scalar cache one stage ahead of their use (nxt), so the DMA addresses never wait for them
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    int nxt[2][2] = {{0, 0}, {0, 0}};
+    auto fetch_rows = [&](int st) {
+        if (IDX && st < nst) {
+            const int pw = r_begin + st * WD_RS + 2 * wu;               // even: 8-byte aligned pairs
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int2 v = *(const int2*)(a.ridx + pw + 8 * i);
+                nxt[i][0] = pw + 8 * i < count ? v.x : -1;
+                nxt[i][1] = pw + 8 * i + 1 < count ? v.y : -1;
+            }
+        }
+    };
+#define WD_ISSUE_IDX(st)                                                                                                \
+    {                                                                                                                   \
+        float* base = sm + ((st) % WD_NS) * ssz;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                \
+            const int row = hi ? nxt[i][1] : nxt[i][0];                                                                 \
+            const float* xs_ = row >= 0 ? a.X + (size_t)row * a.ldx + xcol : a.zrow + 4 * l31;                          \
+            const float* ys_ = row >= 0 ? a.dY + (size_t)row * a.ldy + ycol : a.zrow + 4 * l31;                         \
+            __builtin_amdgcn_global_load_lds((glb_f*)xs_, (lds_f*)(base + (2 * w + 8 * i) * 128), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds((glb_f*)ys_, (lds_f*)(base + XSZ + (2 * w + 8 * i) * 128), 16, 0, 0);      \
+        }                                                                                                               \
+    }
 #define WD_ISSUE(st)                                                                                                    \
+    if (IDX) { WD_ISSUE_IDX(st) fetch_rows((st) + 1); } else                                                            \
     {                                                                                                                   \
         float* base = sm + ((st) % WD_NS) * ssz;                                                                        \
         const size_t ro = (size_t)(st) * WD_RS;                                                                         \
@@ -855,6 +889,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
                 __builtin_amdgcn_global_load_lds((glb_f*)(x2src + (ro + 8 * i) * a.ldx2), (lds_f*)(base + 2 * XSZ + (2 * w + 8 * i) * 128), 16, 0, 0); \
         }                                                                                                               \
     }
+    fetch_rows(0);
 #pragma unroll
     for (int p = 0; p < WD_NS - 1; ++p)
         if (p < nst) WD_ISSUE(p)
@@ -906,6 +941,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
 #undef WD_FRAG
     }
 #undef WD_ISSUE
+#undef WD_ISSUE_IDX
 
     float* slab = a.slab + (size_t)s * Krows * a.Nn;
 #pragma unroll
@@ -947,7 +983,14 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     }
 }
 
-struct WGKMulti { WGKArgs p[3]; int want_cs[3]; int S[3]; int ty0[4]; int grouped, smax, ssz; };
+struct WGKMulti { WGKArgs p[BMP_WG_MAXP]; int want_cs[BMP_WG_MAXP]; int S[BMP_WG_MAXP]; int ty0[BMP_WG_MAXP + 1]; int n, grouped, smax, ssz; };
+// the problem that owns column tile `by` (ty0[p] <= by < ty0[p + 1]; ty0[n ..] = the launch's tile count)
+__device__ __forceinline__ int wgk_problem(const WGKMulti& m, int by) {
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < BMP_WG_MAXP; ++q) p += (q < m.n && by >= m.ty0[q]) ? 1 : 0;
+    return p;
+}
 // STEP = 1: the launch of bmp_launch_wgrad_fused (same code; a separate symbol so that profiles tell the fused step
 // weight gradients from the co-attention's small three-problem launch)
 template <int STEP>
@@ -962,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
         // the tiles of a split landed on eight different XCDs and every one of them fetched its operands from HBM itself: 658 MB
         // per launch for 291 MB of operands).  G = smax / 8 splits live whole on every XCD; the tiles of the remaining
         // smax % 8 splits fill the XCDs' last slots one by one.
-        const int T = m.ty0[3], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
+        const int T = m.ty0[BMP_WG_MAXP], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
         if (slot < G * T) { bz = xcd * G + slot / T; by = slot % T; }
         else {
             const int r = (slot - G * T) * 8 + xcd;
@@ -970,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
             bz = 8 * G + r / T; by = r % T;
         }
     } else { by = blockIdx.y; bz = blockIdx.z; }
-    const int p = by >= m.ty0[2] ? 2 : (by >= m.ty0[1] ? 1 : 0);
+    const int p = wgk_problem(m, by);
     if (bz >= m.S[p]) return;
     if (m.p[p].X2) wgrad_lds_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, XS, YS);
     else wgrad_lds_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, XS, YS);
@@ -982,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_wgrad_dma_multi(WGKMulti m) {
     extern __shared__ __attribute__((aligned(16))) float wd_sm[];
     int by, bz;
     if (m.grouped) {          // see k_wgrad_lds_multi
-        const int T = m.ty0[3], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
+        const int T = m.ty0[BMP_WG_MAXP], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
         if (slot < G * T) { bz = xcd * G + slot / T; by = slot % T; }
         else {
             const int r = (slot - G * T) * 8 + xcd;
@@ -990,25 +1033,30 @@ __global__ __launch_bounds__(256) void k_wgrad_dma_multi(WGKMulti m) {
             bz = 8 * G + r / T; by = r % T;
         }
     } else { by = blockIdx.y; bz = blockIdx.z; }
-    const int p = by >= m.ty0[2] ? 2 : (by >= m.ty0[1] ? 1 : 0);
+    const int p = wgk_problem(m, by);
     if (bz >= m.S[p]) return;
-    if (m.p[p].X2) wgrad_dma_body<true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
-    else wgrad_dma_body<false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
+    if (m.p[p].ridx) wgrad_dma_body<false, true>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
+    else if (m.p[p].X2) wgrad_dma_body<true, false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
+    else wgrad_dma_body<false, false>(m.p[p], m.want_cs[p], 0, by - m.ty0[p], bz, wd_sm, m.ssz);
 }
 
 // Launches k_wgrad_dma_multi<STEP> when every problem of the launch can take the DMA body (whole 16-byte pieces in range:
 // K and Nn at least 4 and multiples of 4 -- wgrad_use_lds --, no one-hot operand), else k_wgrad_lds_multi<STEP>.
 // BMP_WGRAD_DMA=0: always the register-staged kernel.
+static bool wgrad_dma_enabled() {
+    static const int on = [] { const char* e = getenv("BMP_WGRAD_DMA"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
 template <int STEP>
 static int wgrad_multi_launch(WGKMulti& m, int n, const dim3& grid, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("BMP_WGRAD_DMA"); return e ? atoi(e) : 1; }();
-    bool ok = on != 0, x2 = false;
+    bool ok = wgrad_dma_enabled(), x2 = false;
     for (int p = 0; p < n; ++p) {
         if (m.S[p] == 0) continue;
         ok = ok && !m.p[p].onehot && m.p[p].K >= 4 && m.p[p].Nn >= 4 && (m.p[p].rows_per_split % WD_RS) == 0 && (m.p[p].N % WD_RS) == 0;
         x2 = x2 || m.p[p].X2 != nullptr;
     }
     if (!ok) {
+        for (int p = 0; p < n; ++p) BMP_REQUIRE(m.p[p].ridx == nullptr);       // row lists exist in the LDS-DMA body only
         hipLaunchKernelGGL((k_wgrad_lds_multi<STEP>), grid, dim3(256), 0, st, m);
         return 0;
     }
@@ -1023,7 +1071,7 @@ static int wgrad_multi_launch(WGKMulti& m, int n, const dim3& grid, hipStream_t 
 // is more than one column tile to share operands; else the plain (tile, split) grid.  BMP_WGRAD_XCD=0: always the plain grid.
 static dim3 wgrad_grouped_grid(WGKMulti& m, int smax) {
     static const int on = [] { const char* e = getenv("BMP_WGRAD_XCD"); return e ? atoi(e) : 1; }();
-    const int T = m.ty0[3];
+    const int T = m.ty0[BMP_WG_MAXP];
     m.smax = smax; m.grouped = 0;
     if (on && T > 1 && smax >= 8) {
         const int G = smax >> 3;
@@ -1041,11 +1089,13 @@ struct RedProb {
     float* out; int ldo, accumulate; float* cs_out; int cs_accumulate;
     float* wout; int ldwo, w_col0;          // rows K + 1 .. K + 4: weighted column sums of the columns >= w_col0
 };
-struct RedMulti { RedProb p[3]; int b0[4]; };
+struct RedMulti { RedProb p[BMP_WG_MAXP]; int b0[BMP_WG_MAXP + 1]; int n; };
 __global__ __launch_bounds__(256) void k_reduce_multi(RedMulti m) {
     __shared__ float red[4][64];
     const int bx = blockIdx.x;
-    const int pi = bx >= m.b0[2] ? 2 : (bx >= m.b0[1] ? 1 : 0);
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < BMP_WG_MAXP; ++k) pi += (k < m.n && bx >= m.b0[k]) ? 1 : 0;
     const RedProb& q = m.p[pi];
     const size_t total = (size_t)q.Krows * q.Nn_phys;
     const size_t slab_sz = (size_t)q.Krows * q.Nn;
@@ -1181,7 +1231,7 @@ int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st) {
 static void wgrad_multi_plan(const WGArgs* a, int n, int* S, int* rps, int* ty0) {
     int tiles = 0;
     for (int p = 0; p < n; ++p) { ty0[p] = tiles; tiles += (a[p].Nn + 127) / 128; }
-    for (int p = n; p <= 3; ++p) ty0[p] = tiles;
+    for (int p = n; p <= BMP_WG_MAXP; ++p) ty0[p] = tiles;
     for (int p = 0; p < n; ++p) {
         int s = 512 / tiles;
         int max_s = a[p].N / 256;
@@ -1195,7 +1245,7 @@ static void wgrad_multi_plan(const WGArgs* a, int n, int* S, int* rps, int* ty0)
 }
 
 size_t bmp_wgrad_multi_ws_floats(const WGArgs* a, int n) {
-    int S[3], rps[3], ty0[4];
+    int S[3], rps[3], ty0[BMP_WG_MAXP + 1];
     wgrad_multi_plan(a, n, S, rps, ty0);
     size_t tot = 0;
     for (int p = 0; p < n; ++p) tot += (size_t)S[p] * (a[p].K + 1) * a[p].Nn;
@@ -1205,8 +1255,9 @@ size_t bmp_wgrad_multi_ws_floats(const WGArgs* a, int n) {
 int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
     BMP_REQUIRE(n >= 1 && n <= 3 && ws != nullptr);
     WGKMulti m; memset(&m, 0, sizeof(m));
+    m.n = n;
     int rps[3];
-    for (int p = 0; p < n; ++p) BMP_REQUIRE(a[p].K <= 128 && !a[p].X2 && !a[p].onehot && wgrad_use_lds(a[p]));
+    for (int p = 0; p < n; ++p) BMP_REQUIRE(a[p].K <= 128 && !a[p].X2 && !a[p].onehot && !a[p].ridx && wgrad_use_lds(a[p]));
     wgrad_multi_plan(a, n, m.S, rps, m.ty0);
     float* slab[3];
     size_t off = 0;
@@ -1241,43 +1292,68 @@ int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st) {
 }
 
 // ---- fused form: all problems share the row range, one GEMM launch + one reduction launch ----
+// A problem with a row list weighs rfrac of a full one: the launch's 512 slots go to (column tiles x row parts) in proportion,
+// so that a part of a listed problem holds about as many rows as a part of a full one -- when the lists are as long as
+// expected; any other length is still computed correctly, in parts of another size (wgrad_dma_body).
 static void wgrad_fused_plan(const WGArgs* a, int n, int* S, int* rps, int* ty0) {
     int tiles = 0;
-    for (int p = 0; p < n; ++p) { ty0[p] = tiles; if (!a[p].zero_only) tiles += (a[p].Nn + 127) / 128; }
-    for (int p = n; p <= 3; ++p) ty0[p] = tiles;
+    double wtiles = 0.0;
     for (int p = 0; p < n; ++p) {
-        int s = 512 / (tiles > 0 ? tiles : 1);        // 2 workgroups per CU and no second round
+        ty0[p] = tiles;
+        if (!a[p].zero_only) {
+            const int t = (a[p].Nn + 127) / 128;
+            tiles += t;
+            wtiles += t * (a[p].ridx ? (double)a[p].rfrac : 1.0);
+        }
+    }
+    for (int p = n; p <= BMP_WG_MAXP; ++p) ty0[p] = tiles;
+    for (int p = 0; p < n; ++p) {
+        int s = (int)(512.0 / (wtiles > 0.0 ? wtiles : 1.0));        // 2 workgroups per CU and no second round
         int max_s = a[p].N / 256;                     // at least 8 stages per split
         if (max_s < 1) max_s = 1;
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
         int r = (a[p].N + s - 1) / s;
         r = (r + 31) & ~31;
-        rps[p] = r; S[p] = a[p].zero_only ? 0 : (a[p].N + r - 1) / r;
+        rps[p] = r;
+        const int sfull = (a[p].N + r - 1) / r;
+        if (a[p].zero_only) S[p] = 0;
+        else if (a[p].ridx) { int sp = (int)(sfull * (double)a[p].rfrac + 0.5); S[p] = sp < 1 ? 1 : (sp > sfull ? sfull : sp); }
+        else S[p] = sfull;
     }
 }
 
 size_t bmp_wgrad_fused_ws_floats(const WGArgs* a, int n) {
-    int S[3], rps[3], ty0[4];
+    int S[BMP_WG_MAXP], rps[BMP_WG_MAXP], ty0[BMP_WG_MAXP + 1];
     wgrad_fused_plan(a, n, S, rps, ty0);
-    size_t tot = 0;
+    size_t tot = 128;                                // the zero row of the listed problems
     for (int p = 0; p < n; ++p) tot += (size_t)S[p] * (a[p].K + 5) * a[p].Nn;
     return tot;
 }
 
+bool bmp_wgrad_fused_lists_ok(int N) { return wgrad_dma_enabled() && N > 0 && (N % WD_RS) == 0; }
+
 int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, int kid) {
-    BMP_REQUIRE(n >= 1 && n <= 3 && ws != nullptr);
+    BMP_REQUIRE(n >= 1 && n <= BMP_WG_MAXP && ws != nullptr);
     WGKMulti m; memset(&m, 0, sizeof(m));
     RedMulti r; memset(&r, 0, sizeof(r));
-    int rps[3];
+    m.n = n; r.n = n;
+    int rps[BMP_WG_MAXP];
+    bool listed = false;
     for (int p = 0; p < n; ++p) {
         BMP_REQUIRE(a[p].K <= 128 && !a[p].onehot && (a[p].zero_only || wgrad_use_lds(a[p])));
+        if (a[p].ridx) {
+            BMP_REQUIRE(a[p].rcnt && !a[p].X2 && !a[p].wrow && a[p].skip_n == 0 && !a[p].zero_only && bmp_wgrad_fused_lists_ok(a[p].N));
+            listed = true;
+        }
         BMP_REQUIRE(a[p].skip_n == 0 || ((a[p].skip_at & 127) == 0 && (a[p].skip_n & 3) == 0));
         BMP_REQUIRE(a[p].N == a[0].N);
         BMP_REQUIRE(!a[p].wrow || (a[p].cs && a[p].wout && a[p].skip_n == 0 && (a[p].w_col0 & 127) == 0));
     }
     wgrad_fused_plan(a, n, m.S, rps, m.ty0);
-    size_t off = 0;
+    float* zrow = ws;                                // 128 zero floats: what a listed problem reads past the end of its list
+    if (listed) { hipError_t e = hipMemsetAsync(zrow, 0, 128 * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+    size_t off = 128;
     int smax = 0, rb = 0;
     double flops = 0, bytes = 0;
     for (int p = 0; p < n; ++p) {
@@ -1289,6 +1365,7 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
         RedProb& q = r.p[p];
         const int nw = (a[p].wrow && want_cs) ? 4 : 0;
         k.wrow = nw ? a[p].wrow : nullptr; k.w_col0 = a[p].w_col0;
+        if (a[p].ridx) { k.ridx = a[p].ridx; k.rcnt = a[p].rcnt; k.zrow = zrow; k.nsplit = m.S[p]; }
         m.p[p] = k;
         q.slab = ws + off; q.S = m.S[p]; q.K = a[p].K; q.Krows = a[p].K + want_cs + nw; q.Nn = a[p].Nn;
         q.wout = a[p].wout; q.ldwo = a[p].ldwo; q.w_col0 = a[p].w_col0;
@@ -1307,8 +1384,8 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
         if (a[p].zero_only && a[p].accumulate) blocks = 0;          // nothing to add
         rb += blocks;
     }
-    for (int p = n; p <= 3; ++p) r.b0[p] = rb;
-    if (m.ty0[3] > 0) {
+    for (int p = n; p <= BMP_WG_MAXP; ++p) r.b0[p] = rb;
+    if (m.ty0[BMP_WG_MAXP] > 0) {
         BmpProfScope prof(BMP_KCLS_WGRAD, flops, bytes, st, kid);
         const dim3 grid = wgrad_grouped_grid(m, smax);
         const int rc = wgrad_multi_launch<1>(m, n, grid, st);

@@ -70,14 +70,21 @@ struct WGArgs {
     // ... and weighted column sums riding along: wout[e, j - w_col0] (=|+=) sum_rows wrow[row, e] * dY[row, j] for the
     // logical columns j >= w_col0 (e < 4; wrow [N x 4]): the per-bond-type bias gradient of a RelGCN layer
     const float* wrow = nullptr; int w_col0 = 0; float* wout = nullptr; int ldwo = 0;
+    // ... and a row LIST (round 4): the problem sums over the rows ridx[0 .. *rcnt) only (ascending row numbers; the other
+    // rows of dY are known to be zero: the per-bond-type blocks G_e of a propagation step, bmp_type_rows).  ridx / rcnt are
+    // DEVICE arrays (no host copy of the count exists): the launch splits the list into round(S * rfrac) parts whatever
+    // the count turns out to be; rfrac = the expected share of listed rows (only the balance of the launch depends on it).
+    const int* ridx = nullptr; const int* rcnt = nullptr; float rfrac = 1.f;
 };
 size_t bmp_wgrad_ws_floats(int N, int K, int Nn);
 int bmp_launch_wgrad(const WGArgs& a, float* ws, hipStream_t st);
 // n <= 3 independent problems (K <= 128, no X2) in ONE GEMM launch: for launches of a few tiles each
 size_t bmp_wgrad_multi_ws_floats(const WGArgs* a, int n);
 int bmp_launch_wgrad_multi(const WGArgs* a, int n, float* ws, hipStream_t st);
-// n <= 3 problems over the SAME rows (K <= 128; X2, column skips and zero-only problems allowed) as ONE GEMM launch and
-// ONE reduction launch: the weight gradients of a fused GGNN step / RelGCN layer.
+// n <= BMP_WG_MAXP problems over the SAME rows (K <= 128; X2, column skips, zero-only problems and row lists allowed) as ONE
+// GEMM launch and ONE reduction launch: the weight gradients of a fused GGNN step / RelGCN layer.
+#define BMP_WG_MAXP 8
+bool bmp_wgrad_fused_lists_ok(int N);        // row lists need the LDS-DMA body (BMP_WGRAD_DMA != 0, N a multiple of 16)
 size_t bmp_wgrad_fused_ws_floats(const WGArgs* a, int n);
 int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, int kid);
 

@@ -145,9 +145,18 @@ int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const
                       const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
                       const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
 size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
+/* type_rows [4 x N] / type_cnt [4] (both optional, NULL together): bmp_type_rows of the batch's TRANSPOSED CSR.  A row's
+ * gathered gradient G_e is an exact zero unless the row has a bond of type e (73 / 19 / 2 / 52 % of the rows of a DDI batch for
+ * single / double / triple / aromatic): with the lists the four per-type blocks of o1 sum over their rows only. */
 int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first,
-                        float* o1, float* o2, float* dUcT, float* cs, int accumulate, float* ws, size_t ws_floats,
-                        bmp_stream_t stream);
+                        float* o1, float* o2, float* dUcT, float* cs, int accumulate, const int* type_rows, const int* type_cnt,
+                        float* ws, size_t ws_floats, bmp_stream_t stream);
+
+/* Rows by bond type of a CSR (no reference counterpart: the reference's dense (mb, 4, A, A) adjacency multiplies the zeros,
+ * models/ggnn.py:229-242): idx[e * N + p] = the p-th row, ascending, that holds an entry of type e; cnt[e] = their number
+ * (device arrays; the count never visits the host).  ws: bmp_type_rows_ws_ints(N) ints.  Fixed order, no atomics. */
+size_t bmp_type_rows_ws_ints(int N);
+int bmp_type_rows(const int* csr_ptr, const int* csr_col, int N, int* idx, int* cnt, int* ws, bmp_stream_t stream);
 
 /* One whole RelGCN layer, fused per 128-row tile -- RelGCNUpdate.__call__ models/update/relgcn_update.py:24-44 with
  * the tanh of models/relgcn.py:71: out = act(h W_s^T + b_s + sum_e adj'_e (W_e h + b_e)), the 1/degree of rescale_adj
@@ -166,7 +175,8 @@ int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_til
                          float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
 size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d);
 int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
-                           float* cs, int accumulate, float* ws, size_t ws_floats, bmp_stream_t stream);
+                           float* cs, int accumulate, const int* type_rows, const int* type_cnt, float* ws, size_t ws_floats,
+                           bmp_stream_t stream);          /* type_rows / type_cnt: as bmp_ggnn_step_wgrad */
 
 /* Gated-sum readout -- GGNN.readout models/ggnn.py:333-341 and GGNNReadout.__call__
  * models/readout/ggnn_readout.py:42-57.  g[mol] = sum_rows w * sigmoid(i(.)) * act_j(j(.)).

@@ -1,0 +1,95 @@
+"""Rows by bond type (bmp_type_rows) and the weight-gradient launches that walk them (round 4).
+
+The gathered gradient G_e of a row is an exact zero unless the row has a bond of type e, so the per-type blocks of a step's
+weight gradients may sum over the listed rows only: the lists must be exactly those rows (bit-exact integer work, against
+numpy), and the step's / layer's weight gradients with the lists must equal the all-rows launches up to float32 summation
+order (the rows are dealt to other workgroups) -- and, like every other result, the float64 oracle (the oracle tests of
+test_gpu_ops.py / test_gpu_fullsize_backward.py run with the lists on)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch(n_pairs=96, seed=3):
+    from bmp import packed, synth
+    store = synth.make_store(60, seed=seed, n_lo=2, n_hi=70, n_mean=20)
+    ms = packed.MolStore(store)
+    rs = np.random.RandomState(seed)
+    i1, i2 = rs.randint(0, 60, n_pairs), rs.randint(0, 60, n_pairs)
+    return packed.pack_from_store(ms, [i1, i2], device=torch.device("cuda:0"))
+
+
+def test_type_rows_are_the_rows_with_an_entry_of_the_type():
+    pb = _batch()
+    idx, cnt = pb.type_rows_T()
+    torch.cuda.synchronize()
+    N = pb.n_rows
+    ptr, col = pb.csrT_ptr.cpu().numpy(), pb.csrT_col.cpu().numpy()
+    rows = np.repeat(np.arange(N), np.diff(ptr))
+    idx, cnt = idx.cpu().numpy().reshape(4, N), cnt.cpu().numpy()
+    for e in range(4):
+        want = np.unique(rows[(col & 3) == e])
+        assert cnt[e] == len(want)
+        assert np.array_equal(idx[e, :cnt[e]], want)          # ascending, exact
+    assert cnt[0] > cnt[1] > cnt[2] >= 0 and pb.type_rows_T()[0] is pb._cache["type_rows_T"][0]        # built once, kept
+
+
+@pytest.mark.parametrize("first", [True, False])
+@pytest.mark.parametrize("d", [64, 128])
+def test_step_wgrad_with_row_lists_equals_all_rows(d, first):
+    from bmp import _lib
+    from bmp._lib import check, ptr, stream
+    from parity_util import close
+    L = _lib.lib()
+    pb = _batch(160, seed=5)
+    dev = pb.device
+    N = pb.n_rows
+    g = torch.Generator().manual_seed(d + int(first))
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    h, m, rz = rnd(N, d), rnd(N, d), torch.rand(N, 2 * d, generator=g).to(dev)
+    # a gda as the backward writes it: the G_e block of a row is zero unless the row has a bond of the type
+    gda = rnd(N, 7 * d) * 1e-2
+    idx, cnt = pb.type_rows_T()
+    torch.cuda.synchronize()
+    mask = torch.zeros(4, N, device=dev)
+    for e in range(4):
+        mask[e, idx[e * N: e * N + int(cnt[e])].long()] = 1.0
+    for e in range(4):
+        gda[:, e * d:(e + 1) * d] *= mask[e][:, None]
+    out = []
+    for lists in (False, True):
+        o1, o2, dU, cs = (torch.full(s_, 7.0, device=dev) for s_ in ((d, 7 * d), (d, 3 * d), (d, d), (7 * d,)))
+        nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
+        ws = torch.empty(nws, device=dev)
+        for acc in (0, 1):                   # written, then accumulated into (tied layers): twice the sums
+            check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, int(first), ptr(o1), ptr(o2), ptr(dU), ptr(cs), acc,
+                                        ptr(idx if lists else None), ptr(cnt if lists else None), ptr(ws), nws, stream()), "wgrad")
+        torch.cuda.synchronize()
+        out.append((o1.clone(), o2.clone(), dU.clone(), cs.clone()))
+    ref = 2.0 * (h.double().t() @ gda.double())
+    if first:
+        ref[:, 4 * d:5 * d] = 0.0
+    close(out[1][0], ref, f"o1 with lists vs float64 (d {d}, first {first})", tol=2e-5)
+    for name, a_, b_ in zip(("o1", "o2", "dUcT", "cs"), out[0], out[1]):
+        close(b_, a_.double(), f"{name} with lists vs all rows", tol=2e-5, floor=1e-3 * float(a_.abs().max()) + 1e-12)
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])       # o2 / dUcT: the same products in the same order
+
+
+def test_lists_off_switch_reaches_the_library():
+    """BMP_WGRAD_LISTS=0 (bench.py's A/B): the planned step passes no lists and still equals the oracle (the all-rows launches are
+    what rounds 1-3 tested); checked in a child process because the switch is read at import."""
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]\n"
+            "from bmp import functional as Fn\n"
+            "assert Fn._WGRAD_LISTS is False and Fn.type_rows(None) == (None, None)\n"
+            "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', %r, '-k', 'fused_step_fwd_bwd and 128']))\n"
+            % (ROOT, os.path.join(ROOT, "gcn-bmp_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "test_gpu_ops.py")))
+    env = dict(os.environ, BMP_WGRAD_LISTS="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
