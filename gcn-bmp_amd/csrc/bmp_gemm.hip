@@ -849,34 +849,45 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     // the counted wait below leaves the youngest NLD loads of a wave outstanding, i.e. the next stage's X / dY / X2 pieces
     const int WOFF = (HAS_X2 ? 3 : 2) * XSZ;
     const float* wsrc = do_w ? a.wrow + (size_t)(r_begin + (lane & 15)) * 4 : nullptr;
-    // IDX: the four row numbers a wave needs per stage (rows 2 w, 2 w + 1 of the stage's two 8-row halves) are wave-uniform:
-    // fetched through the scalar cache one stage ahead of their use (nxt), so the DMA addresses never wait for them
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    int nxt[2][2] = {{0, 0}, {0, 0}};
-    auto fetch_rows = [&](int st) {
-        if (IDX && st < nst) {
-            const int pw = r_begin + st * WD_RS + 2 * wu;               // even: 8-byte aligned pairs
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int2 v = *(const int2*)(a.ridx + pw + 8 * i);
-                nxt[i][0] = pw + 8 * i < count ? v.x : -1;
-                nxt[i][1] = pw + 8 * i + 1 < count ? v.y : -1;
-            }
-        }
-    };
+    // IDX: the four row numbers a wave needs per stage (rows 2 w, 2 w + 1 of the stage's two 8-row halves) are wave-uniform.
+    // They are read through the SCALAR cache (the list was written by an earlier kernel: a constant-address-space view), one
+    // stage ahead of their use: scalar loads count in lgkmcnt, so neither the compiler's wait for them nor the counted vmcnt
+    // waits of the DMA pipeline see each other (as per-lane vector loads the compiler drained the DMA queue -- vmcnt(0) --
+    // before every use: one stage in flight, 212 us instead of 185).  Operand bases in registers: the waits' memory clobber
+    // would re-read the argument block every trip.
+    typedef int wd_v2i __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(4))) wd_v2i wd_cv2i;
+    typedef const __attribute__((address_space(4))) int wd_cint;
+    wd_cint* const ridx_ = IDX ? (wd_cint*)(uintptr_t)a.ridx : nullptr;
+    const float* const xb_ = a.X; const float* const yb_ = a.dY; const float* const zr_ = IDX ? a.zrow + 4 * l31 : nullptr;
+    const int ldx_ = a.ldx, ldy_ = a.ldy;
+    const int cap_ = a.N;
+    const int wu_ = __builtin_amdgcn_readfirstlane(w);
+    wd_v2i rva = {0, 0}, rvb = {0, 0};
+#define WD_FETCH(st)                                                                                                    \
+    if (IDX && (st) < nst) {                                                                                            \
+        int pw = r_begin + (st) * WD_RS + 2 * wu_;              /* even: 8-byte aligned pairs */                        \
+        pw = __builtin_amdgcn_readfirstlane(pw < cap_ - 10 ? pw : cap_ - 10);                                           \
+        rva = *(wd_cv2i*)(ridx_ + pw);                                                                                  \
+        rvb = *(wd_cv2i*)(ridx_ + pw + 8);                                                                              \
+    }
 #define WD_ISSUE_IDX(st)                                                                                                \
     {                                                                                                                   \
         float* base = sm + ((st) % WD_NS) * ssz;                                                                        \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                \
-            const int row = hi ? nxt[i][1] : nxt[i][0];                                                                 \
-            const float* xs_ = row >= 0 ? a.X + (size_t)row * a.ldx + xcol : a.zrow + 4 * l31;                          \
-            const float* ys_ = row >= 0 ? a.dY + (size_t)row * a.ldy + ycol : a.zrow + 4 * l31;                         \
-            __builtin_amdgcn_global_load_lds((glb_f*)xs_, (lds_f*)(base + (2 * w + 8 * i) * 128), 16, 0, 0);            \
-            __builtin_amdgcn_global_load_lds((glb_f*)ys_, (lds_f*)(base + XSZ + (2 * w + 8 * i) * 128), 16, 0, 0);      \
-        }                                                                                                               \
+        const int p0 = r_begin + (st) * WD_RS + 2 * w + hi;                                                             \
+        const int row0 = p0 < count ? (hi ? rva.y : rva.x) : -1, row1 = p0 + 8 < count ? (hi ? rvb.y : rvb.x) : -1;     \
+        WD_FETCH((st) + 1)                                                                                              \
+        const float* x0 = row0 >= 0 ? xb_ + (size_t)row0 * ldx_ + xcol : zr_;                                           \
+        const float* y0 = row0 >= 0 ? yb_ + (size_t)row0 * ldy_ + ycol : zr_;                                           \
+        const float* x1 = row1 >= 0 ? xb_ + (size_t)row1 * ldx_ + xcol : zr_;                                           \
+        const float* y1 = row1 >= 0 ? yb_ + (size_t)row1 * ldy_ + ycol : zr_;                                           \
+        __builtin_amdgcn_global_load_lds((glb_f*)x0, (lds_f*)(base + (2 * w) * 128), 16, 0, 0);                         \
+        __builtin_amdgcn_global_load_lds((glb_f*)y0, (lds_f*)(base + XSZ + (2 * w) * 128), 16, 0, 0);                   \
+        __builtin_amdgcn_global_load_lds((glb_f*)x1, (lds_f*)(base + (2 * w + 8) * 128), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((glb_f*)y1, (lds_f*)(base + XSZ + (2 * w + 8) * 128), 16, 0, 0);               \
     }
 #define WD_ISSUE(st)                                                                                                    \
-    if (IDX) { WD_ISSUE_IDX(st) fetch_rows((st) + 1); } else                                                            \
+    if (IDX) { WD_ISSUE_IDX(st) } else                                                                                  \
     {                                                                                                                   \
         float* base = sm + ((st) % WD_NS) * ssz;                                                                        \
         const size_t ro = (size_t)(st) * WD_RS;                                                                         \
@@ -889,7 +900,8 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
                 __builtin_amdgcn_global_load_lds((glb_f*)(x2src + (ro + 8 * i) * a.ldx2), (lds_f*)(base + 2 * XSZ + (2 * w + 8 * i) * 128), 16, 0, 0); \
         }                                                                                                               \
     }
-    fetch_rows(0);
+    static_assert(!IDX || NI == 2, "the listed form issues the two 8-row halves of a 16-row stage by hand");
+    WD_FETCH(0)
 #pragma unroll
     for (int p = 0; p < WD_NS - 1; ++p)
         if (p < nst) WD_ISSUE(p)
@@ -942,6 +954,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     }
 #undef WD_ISSUE
 #undef WD_ISSUE_IDX
+#undef WD_FETCH
 
     float* slab = a.slab + (size_t)s * Krows * a.Nn;
 #pragma unroll
@@ -983,7 +996,30 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     }
 }
 
-struct WGKMulti { WGKArgs p[BMP_WG_MAXP]; int want_cs[BMP_WG_MAXP]; int S[BMP_WG_MAXP]; int ty0[BMP_WG_MAXP + 1]; int n, grouped, smax, ssz; };
+#define BMP_WG_MAXT 32
+struct WGKMulti {
+    WGKArgs p[BMP_WG_MAXP]; int want_cs[BMP_WG_MAXP]; int S[BMP_WG_MAXP]; int ty0[BMP_WG_MAXP + 1]; int n, grouped, smax, ssz;
+    // grouped == 2: a flat grid of exactly the launch's work items (problems with different part counts: row lists).  Item L
+    // is the (L - before(z))-th of the column tiles that have a part z, tiles in descending order of their part counts:
+    // ford[k] = the k-th tile, fs[k] = its part count; before(z) = sum_k min(fs[k], z).
+    int ft; unsigned char ford[BMP_WG_MAXT]; short fs[BMP_WG_MAXT];
+};
+// flat grid -> (column tile, part); false: no such item
+__device__ __forceinline__ bool wgk_flat(const WGKMulti& m, int L, int& by, int& bz) {
+    int lo = 0, hi = m.smax;                 // largest z with before(z) <= L
+    while (hi - lo > 1) {
+        const int z = (lo + hi) >> 1;
+        int b = 0;
+        for (int k = 0; k < m.ft; ++k) b += m.fs[k] < z ? m.fs[k] : z;
+        if (b <= L) lo = z; else hi = z;
+    }
+    int b = 0;
+    for (int k = 0; k < m.ft; ++k) b += m.fs[k] < lo ? m.fs[k] : lo;
+    const int k = L - b;
+    if (k >= m.ft || m.fs[k] <= lo) return false;
+    by = m.ford[k]; bz = lo;
+    return true;
+}
 // the problem that owns column tile `by` (ty0[p] <= by < ty0[p + 1]; ty0[n ..] = the launch's tile count)
 __device__ __forceinline__ int wgk_problem(const WGKMulti& m, int by) {
     int p = 0;
@@ -998,7 +1034,8 @@ __global__ __launch_bounds__(256) void k_wgrad_lds_multi(WGKMulti m) {
     __shared__ __attribute__((aligned(16))) float XS[2][32][WG_LD];
     __shared__ __attribute__((aligned(16))) float YS[2][32][WG_LD];
     int by, bz;
-    if (m.grouped) {
+    if (m.grouped == 2) { if (!wgk_flat(m, blockIdx.x, by, bz)) return; }
+    else if (m.grouped) {
         // XCD-grouped 1-D launch (wgrad_grouped_grid): workgroup L runs on XCD L % 8, and the launch fits the chip's slots, so
         // the workgroups of an XCD are resident together.  All column tiles of a row split then sit on ONE XCD and walk the same
         // rows of X and dY at about the same time: one fetch into that XCD's L2 serves them all (in the (tile, split) grid order
@@ -1024,7 +1061,8 @@ template <int STEP>
 __global__ __launch_bounds__(256) void k_wgrad_dma_multi(WGKMulti m) {
     extern __shared__ __attribute__((aligned(16))) float wd_sm[];
     int by, bz;
-    if (m.grouped) {          // see k_wgrad_lds_multi
+    if (m.grouped == 2) { if (!wgk_flat(m, blockIdx.x, by, bz)) return; }
+    else if (m.grouped) {     // see k_wgrad_lds_multi
         const int T = m.ty0[BMP_WG_MAXP], L = blockIdx.x, xcd = L & 7, slot = L >> 3, G = m.smax >> 3;
         if (slot < G * T) { bz = xcd * G + slot / T; by = slot % T; }
         else {
@@ -1073,6 +1111,24 @@ static dim3 wgrad_grouped_grid(WGKMulti& m, int smax) {
     static const int on = [] { const char* e = getenv("BMP_WGRAD_XCD"); return e ? atoi(e) : 1; }();
     const int T = m.ty0[BMP_WG_MAXP];
     m.smax = smax; m.grouped = 0;
+    {   // problems with different part counts (row lists): exactly the work items, no holes in the grid -- a (tile, part) grid
+        // whose missing parts exit at once leaves some CUs with three resident workgroups and others with one, and the launch
+        // lasts as long as the fullest CU (measured: 213 us against 185 for MORE work)
+        bool same = true;
+        for (int p = 0; p < m.n; ++p) if (m.S[p] != 0 && m.S[p] != smax) same = false;
+        if (!same && T <= BMP_WG_MAXT) {
+            int tp[BMP_WG_MAXT], nt = 0, total = 0;
+            for (int p = 0; p < m.n; ++p)
+                for (int t = m.ty0[p]; t < m.ty0[p + 1]; ++t) if (m.S[p] > 0) { tp[nt++] = t; total += m.S[p]; }
+            auto sof = [&](int t) { int p = 0; while (p + 1 < m.n && t >= m.ty0[p + 1]) ++p; return m.S[p]; };
+            for (int i = 1; i < nt; ++i)                 // insertion sort, descending part count, stable
+                for (int j = i; j > 0 && sof(tp[j]) > sof(tp[j - 1]); --j) { const int x = tp[j]; tp[j] = tp[j - 1]; tp[j - 1] = x; }
+            m.ft = nt;
+            for (int k = 0; k < nt; ++k) { m.ford[k] = (unsigned char)tp[k]; m.fs[k] = (short)sof(tp[k]); }
+            m.grouped = 2;
+            return dim3(total, 1, 1);
+        }
+    }
     if (on && T > 1 && smax >= 8) {
         const int G = smax >> 3;
         const int slots = G * T + ((smax - 8 * G) * T + 7) / 8;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_type_rows_emit(const int* __restrict__ 
 // TRANSPOSED CSR for the backward's gathered gradients G_e).
 extern "C" size_t bmp_type_rows_ws_ints(int N) { return (size_t)((N + 255) / 256) * 4; }
 extern "C" int bmp_type_rows(const int* csr_ptr, const int* csr_col, int N, int* idx, int* cnt, int* ws, hipStream_t st) {
-    BMP_REQUIRE(csr_ptr && csr_col && N > 0 && idx && cnt && ws);
+    BMP_REQUIRE(csr_ptr && N > 0 && idx && cnt && ws);          // (csr_col may be NULL: a batch without a single bond)
     const int nb = (N + 255) / 256;
     hipLaunchKernelGGL(k_type_rows_count, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, N, ws);
     BMP_LAUNCH_CHECK();
