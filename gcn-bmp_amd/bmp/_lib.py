@@ -30,7 +30,7 @@ SIGNATURES = {
     "bmp_embed_bwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _Z, _P]),
     "bmp_msg_fwd": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     "bmp_msg_bwd_ws_floats": (_Z, [_I, _I, _I]),
-    "bmp_msg_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P, _P]),
+    "bmp_msg_bwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P, _P]),
     "bmp_gru_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "bmp_gru_bwd_ws_floats": (_Z, [_I, _I]),
     "bmp_gru_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _Z, _P, _P]),

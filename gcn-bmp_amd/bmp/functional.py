@@ -107,9 +107,10 @@ class MsgFn(Function):
         dbs = torch.empty(d_out, dtype=torch.float32, device=dev) if ctx.has_self else None
         nws = L.bmp_msg_bwd_ws_floats(pb.n_tiles, d_in, d_out)
         ws = _ws(nws, dev)
+        trf, trc = type_rows(pb, forward=True)
         check(L.bmp_msg_bwd(ptr(dout), d_out, ptr(out), d_out, ctx.act, ptr(x), d_in, pb.n_tiles, d_in, d_out,
                             ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(Ws), ptr(agg), ptr(wdeg),
-                            ptr(dx), ptr(dWT), ptr(dbE), ptr(dWsT), ptr(dbs), 0, ptr(ws), nws, stream(), None), "bmp_msg_bwd")
+                            ptr(dx), ptr(dWT), ptr(dbE), ptr(dWsT), ptr(dbs), 0, ptr(trf), ptr(trc), ptr(ws), nws, stream(), None), "bmp_msg_bwd")
         return dx, dWT, dbE, dWsT, (dbs if ctx.has_bs else None), None, None
 
 
@@ -204,11 +205,11 @@ class GRUStateFn(Function):
 _WGRAD_LISTS = os.environ.get("BMP_WGRAD_LISTS", "1") != "0"
 
 
-def type_rows(pb):
-    """(idx, cnt) pointers' tensors of the batch's transposed CSR, or (None, None)."""
-    if not _WGRAD_LISTS:
+def type_rows(pb, forward: bool = False):
+    """(idx, cnt) tensors of the batch's transposed (default) or forward CSR, or (None, None)."""
+    if not _WGRAD_LISTS or pb is None:
         return None, None
-    tr = pb.type_rows_T()
+    tr = pb.type_rows_T(forward=forward)
     return tr if tr is not None else (None, None)
 
 
@@ -889,6 +890,7 @@ class PMsgFn(Function):
             check(L.bmp_msg_fwd(ptr(x), d_in, nt, d_in, d_out, _at(pb.csr_ptr, r0), ptr(pb.csr_col), ptr(pb.csr_val),
                                 ptr(W["WT"]), ptr(W["bE"]), ptr(W.get("WsT")), ptr(W.get("bs")), act, _at(agg, r0), _at(wdeg, r0),
                                 _at(out, r0), d_out, st), "bmp_msg_fwd")
+        type_rows(pb, forward=True)      # (once per batch, on the chain's stream: the backward's side-stream launch walks the lists)
         ctx.save_for_backward(x, agg, wdeg, out)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.act = pb, W, G, state, gkey, act
         _register(state, gkey)
@@ -906,10 +908,11 @@ class PMsgFn(Function):
         acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
         nws = L.bmp_msg_bwd_ws_floats(pb.n_tiles, d_in, d_out)
         ws = _ws(nws, x.device)
+        trf, trc = type_rows(pb, forward=True)           # (built in the forward, on the chain's stream)
         check(L.bmp_msg_bwd(ptr(dout), d_out, ptr(out), d_out, ctx.act, ptr(x), d_in, pb.n_tiles, d_in, d_out,
                             ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat"]), ptr(W.get("Ws")), ptr(agg),
-                            ptr(wdeg), ptr(dx), ptr(G["dWT"]), ptr(G["dbE"]), ptr(G.get("dWsT")), ptr(G.get("dbs")), acc, ptr(ws),
-                            nws, stream(), _side_handle(ctx.state, (x, agg, wdeg, dout, ws))), "bmp_msg_bwd")
+                            ptr(wdeg), ptr(dx), ptr(G["dWT"]), ptr(G["dbE"]), ptr(G.get("dWsT")), ptr(G.get("dbs")), acc, ptr(trf), ptr(trc),
+                            ptr(ws), nws, stream(), _side_handle(ctx.state, (x, agg, wdeg, dout, ws))), "bmp_msg_bwd")
         return dx, None, None, None, None, None, None
 
 

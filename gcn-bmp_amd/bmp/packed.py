@@ -176,14 +176,20 @@ class PackedMolBatch:
         if lo < 0 or hi >= n_atom_types:
             raise ValueError(f"atom ids must lie in [0, {n_atom_types}); this batch has ids in [{lo}, {hi}]")
 
-    def type_rows_T(self):
+    def type_rows_F(self):
+        """``type_rows_T`` for the FORWARD CSR: the rows whose gathered features agg_e are not zero (the unfused message
+        operator's weight gradient dWT = agg^T dpre walks them)."""
+        return self.type_rows_T(forward=True)
+
+    def type_rows_T(self, forward: bool = False):
         """(idx [4 x N] int32, cnt [4] int32), device tensors: the rows of the TRANSPOSED CSR that hold an entry of bond type e
         (``bmp_type_rows``) -- the rows whose gathered gradient G_e is not zero, which is all the step's weight-gradient
         launches need to walk (73 / 19 / 2 / 52 % of a DDI batch's rows).  Built once per batch on the caller's stream (two small
         launches) and kept; host batches: None."""
         if not self.atom_id.is_cuda:
             return None
-        tr = self._cache.get("type_rows_T")
+        key = "type_rows_F" if forward else "type_rows_T"
+        tr = self._cache.get(key)
         if tr is None:
             from . import _lib
             from ._lib import check, ptr, stream
@@ -192,9 +198,10 @@ class PackedMolBatch:
             idx = torch.empty(4 * N, dtype=torch.int32, device=dev)
             cnt = torch.empty(4, dtype=torch.int32, device=dev)
             ws = torch.empty(max(int(L.bmp_type_rows_ws_ints(N)), 4), dtype=torch.int32, device=dev)
-            check(L.bmp_type_rows(ptr(self.csrT_ptr), ptr(self.csrT_col), N, ptr(idx), ptr(cnt), ptr(ws), stream()), "bmp_type_rows")
+            cp, cc = (self.csr_ptr, self.csr_col) if forward else (self.csrT_ptr, self.csrT_col)
+            check(L.bmp_type_rows(ptr(cp), ptr(cc), N, ptr(idx), ptr(cnt), ptr(ws), stream()), "bmp_type_rows")
             tr = (idx, cnt)
-            self._cache["type_rows_T"] = tr
+            self._cache[key] = tr
         return tr
 
     def with_edge_vals(self, csr_val: torch.Tensor, csrT_val: torch.Tensor) -> "PackedMolBatch":

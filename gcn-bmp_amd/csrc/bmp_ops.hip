@@ -111,11 +111,36 @@ extern "C" int bmp_msg_fwd(const float* x, int ldx, int n_tiles, int d_in, int d
     return bmp_launch_rowgemm(a, n_tiles, BMP_EPI_GENERIC, st);
 }
 
+// dWT [4 d_in x d_out] = agg^T . dpre with agg_e (columns [e d_in, (e + 1) d_in)) an exact zero in every row that has no bond of
+// type e: per type and 128-wide K slice one problem over the type's row list (bmp_type_rows of the FORWARD CSR) -- 1.46 N rows
+// instead of 4 N on the DDI batches.  0: the shape does not fit the fused launch (more than BMP_WG_MAXP problems, K slices
+// below 64) and the caller takes the all-rows launch.
+static const float kMsgTypeFrac[4] = {0.78f, 0.24f, 0.05f, 0.58f};
+static int msg_listed_problems(WGArgs* g, const float* agg, const float* dpre, int lddp, int N, int d_in, int d_out, float* dWT, int acc,
+                               const int* type_rows, const int* type_cnt) {
+    const int ks = d_in > 128 ? 128 : d_in, nk = (d_in + ks - 1) / ks;
+    if (4 * nk > BMP_WG_MAXP || (d_in % ks) != 0 || ks < 64 || d_out < 64 || (d_out & 3) || !bmp_wgrad_fused_lists_ok(N) || (N & 31)) return 0;
+    int n = 0;
+    for (int e = 0; e < 4; ++e)
+        for (int k = 0; k < nk; ++k) {
+            g[n] = WGArgs{agg ? agg + e * d_in + k * ks : nullptr, nullptr, 4 * d_in, 0, dpre, lddp, ks, d_out, N,
+                          dWT ? dWT + (size_t)(e * d_in + k * ks) * d_out : nullptr, d_out, acc};
+            g[n].ridx = type_rows + (size_t)e * N; g[n].rcnt = type_cnt + e; g[n].rfrac = kMsgTypeFrac[e];
+            ++n;
+        }
+    return n;
+}
+
 extern "C" size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out) {
     const int N = n_tiles * BMP_R;
     size_t slab = max_sz(bmp_wgrad_ws_floats(N, 4 * d_in, d_out), bmp_wgrad_ws_floats(N, d_in, d_out));
     slab = max_sz(slab, bmp_wgrad_ws_floats(N, 4, d_out));
     slab = max_sz(slab, bmp_colsum_ws_floats(N, d_out));
+    {   // the listed form of dWT (msg_listed_problems)
+        WGArgs g[BMP_WG_MAXP];
+        const int n = msg_listed_problems(g, nullptr, nullptr, 0, N, d_in, d_out, nullptr, 0, (const int*)16, (const int*)16);
+        if (n > 0) slab = max_sz(slab, bmp_wgrad_fused_ws_floats(g, n));
+    }
     return (size_t)N * 4 * d_in + (size_t)N * d_out + slab;
 }
 
@@ -123,8 +148,8 @@ extern "C" size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out) {
 extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ldo, int act, const float* x, int ldx,
                            int n_tiles, int d_in, int d_out, const int* csrT_ptr, const int* csrT_col,
                            const float* csrT_val, const float* Wnat, const float* Ws, const float* agg, const float* wdeg,
-                           float* dx, float* dWT, float* dbE, float* dWsT, float* dbs, int accumulate_w, float* ws,
-                           size_t ws_floats, hipStream_t st, hipStream_t st_w) {
+                           float* dx, float* dWT, float* dbE, float* dWsT, float* dbs, int accumulate_w, const int* type_rows_f,
+                           const int* type_cnt_f, float* ws, size_t ws_floats, hipStream_t st, hipStream_t st_w) {
     BMP_REQUIRE(n_tiles > 0 && (d_in & 7) == 0 && (d_out & 7) == 0 && d_in > 0 && d_out > 0);
     const int acc = accumulate_w ? 1 : 0;          // the weight gradients add into their outputs (a tied layer's later calls)
     BMP_REQUIRE(ws_floats >= bmp_msg_bwd_ws_floats(n_tiles, d_in, d_out));
@@ -165,8 +190,15 @@ extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ld
     if ((rc = bmp_launch_gather_bwd(dagg, N, d_in, csrT_ptr, csrT_col, csrT_val, dx, d_in, accumulate, st))) return rc;
     // weight gradients
     {
-        WGArgs g{agg, nullptr, 4 * d_in, 0, dpre, lddp, 4 * d_in, d_out, N, dWT, d_out, acc};
-        if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
+        WGArgs gl[BMP_WG_MAXP];
+        const int nl = (type_rows_f && type_cnt_f && ((uintptr_t)agg & 15) == 0 && ((uintptr_t)dpre & 15) == 0 && (lddp & 3) == 0)
+                           ? msg_listed_problems(gl, agg, dpre, lddp, N, d_in, d_out, dWT, acc, type_rows_f, type_cnt_f) : 0;
+        if (nl > 0) {
+            if ((rc = bmp_launch_wgrad_fused(gl, nl, slab, st_w, BMP_KID_WGRAD_STEP))) return rc;
+        } else {
+            WGArgs g{agg, nullptr, 4 * d_in, 0, dpre, lddp, 4 * d_in, d_out, N, dWT, d_out, acc};
+            if ((rc = bmp_launch_wgrad(g, slab, st_w))) return rc;
+        }
     }
     {
         WGArgs g{wdeg, nullptr, 4, 0, dpre, lddp, 4, d_out, N, dbE, d_out, acc};

@@ -84,7 +84,10 @@ size_t bmp_msg_bwd_ws_floats(int n_tiles, int d_in, int d_out);
 int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ldo, int act, const float* x, int ldx, int n_tiles,
                 int d_in, int d_out, const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat,
                 const float* Ws, const float* agg, const float* wdeg, float* dx, float* dWT, float* dbE, float* dWsT,
-                float* dbs, int accumulate_w, float* ws, size_t ws_floats, bmp_stream_t stream, bmp_stream_t stream_w);
+                float* dbs, int accumulate_w, const int* type_rows_f, const int* type_cnt_f, float* ws, size_t ws_floats,
+                bmp_stream_t stream, bmp_stream_t stream_w);
+/* (type_rows_f / type_cnt_f: optional bmp_type_rows lists of the FORWARD CSR -- the rows whose gathered features agg_e are not
+ *  zero: dWT = agg^T . dpre then sums over them only, per bond type) */
 
 /* GRU node update -- chainer links.GRU (StatefulGRU) at models/ggnn.py:132,254-262
  * (models/update/ggnn_update.py:28,61).  first != 0 selects the first-call-after-reset branch.
