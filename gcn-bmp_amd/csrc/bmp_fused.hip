@@ -62,6 +62,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv, nrows);
     __syncthreads();
     if (!grp_live) return;                   // a short tile: this half has no rows
+    const RowOrder ro = FZ_ROW_ORDER();      // the half's rows by (rare bond type, row): the order of the message phase
+    const int bi = wr & 1;                   // (RB == 1: this wave's block inside its half)
 
     // one propagation step on the resident tile (Hs): message, gates, h'.  A generic lambda so that the first call after reset
     // (no r gate, no U term: FST) and the later calls are two instances of the same text inside ONE kernel (TS: all T steps of
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
             if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             grp_sync(gs);
             const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-            if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
+            if (any) tile_mma_msg<VAR, 1, RB>(nrb, e, ro.nbr, bi, acc_m, Aw, LD, Bp, ldw, D, rot, &pre);
             FZ_GSYNC();
         }
         // first B fragments of the h-part of the gates: requested now, used after the m epilogue and its barrier
@@ -100,19 +102,21 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
         for (int g = 0; g < NG; ++g) { Bh[g] = base_h + 4 * D * g; Bm[g] = base_m + 4 * D * g; }
         BPre<NG> pre_h;
         tile_b_prefetch<NG>(pre_h, (const float* const (&)[NG])Bh, (const int (&)[NG])ldwg, D, rot);
-        // m -> LDS (A operand of the gates) and HBM (saved for the backward)
+        // m -> LDS (A operand of the gates) and HBM (saved for the backward).  The accumulators hold the rows in the message
+        // phase's order: accumulator position -> row through ro.perm; from here on everything is in packed row order again
         {
-            const AccBuf mo = acc_buf<D>(om, row0, lrow, col);
+            const AccBuf mo = acc_buf<D>(om, row0, 0, col);
             float be[4];
     #pragma unroll
             for (int e = 0; e < 4; ++e) be[e] = bEs[e * D + col];
             FZ_FOR_ACC {
-                const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+                const int tp = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);          // position in the tile
+                const int r = (tp & 64) + ro.perm[tp];                                // its row
                 const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
                 const float v = __builtin_fmaf(wd4[3], be[3], __builtin_fmaf(wd4[2], be[2], __builtin_fmaf(wd4[1], be[1],
                                                __builtin_fmaf(wd4[0], be[0], acc_m[0][rb][reg]))));
-                Al[LOFF(rb, reg)] = v;
-                if (save) acc_st<D>(mo, rb, reg, v);
+                As[r * LD + col] = v;
+                if (save) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), mo.rs, mo.vo + r * D * 4, 0, 0);
             }
         }
         FZ_GSYNC();
@@ -288,20 +292,29 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     BPre<2> pre_c;
     tile_b_prefetch<2>(pre_c, Bc, ld2, D, rot);
     __syncthreads();                         // whole workgroup: the staged CSR and the counters are visible
+    // The half's rows by (rare bond type, row): every MFMA of this kernel takes its A rows in that order (aoff), so all the
+    // accumulators line up with the message backward's, where the order pays; what leaves an accumulator for a row-indexed
+    // LDS tile (d(r*h), dm, dh) looks its row up (FZ_ROWOF).
+    const RowOrder ro = FZ_ROW_ORDER();
+    const int bi = wr & 1;
+    int aoff[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { const int tp = wrow0 + rb * 32 + l31; aoff[rb] = (((tp & 64) + ro.perm[tp]) - (wrow0 + l31)) * LD; }
+#define FZ_ROWOF(rb, reg) ((lrow & 64) + ro.perm[lrow + (rb) * 32 + ((reg) & 3) + 8 * ((reg) >> 2)])
 
     f32x16 acc_x[2][RB];                     // [0] = dh, [1] = dm
     zero_acc(acc_x[0]); zero_acc(acc_x[1]);
-    tile_mma_n<VAR, 2, RB>(nrb, acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c);       // [dh | dm] += da_c . A_c
+    tile_mma_n<VAR, 2, RB>(nrb, acc_x, Xw, LD, Bc, ld2, D, rot, &pre_c, aoff); // [dh | dm] += da_c . A_c
     if (!first) {
         f32x16 acc_d[1][RB];                 // d(r*h) = da_c . U
         zero_acc(acc_d[0]);
         {
             const float* const Bu[1] = {a.Uc + (size_t)(4 * hi) * D + 4 * col};
             const int ldu[1] = {D};
-            tile_mma_n<VAR, 1, RB>(nrb, acc_d, Xw, LD, Bu, ldu, D, rot);
+            tile_mma_n<VAR, 1, RB>(nrb, acc_d, Xw, LD, Bu, ldu, D, rot, nullptr, aoff);
         }
         FZ_GSYNC();                          // all waves of this half done with da_c in X
-        FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_d[0][rb][reg]; }
+        FZ_FOR_ACC { Xs[FZ_ROWOF(rb, reg) * LD + col] = acc_d[0][rb][reg]; }
         f32x4 r4[NV], h4[NV];                // in flight across the group barrier
 #pragma unroll
         for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) { r4[v] = rm_ld<D, 2 * D>(b_rz, v); h4[v] = rm_ld<D, D>(b_h, v); }
@@ -319,16 +332,16 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         FZ_GSYNC();
         {
             const float* const Br[2] = {Ar_h, Ar_h + 4 * D};
-            tile_mma_n<VAR, 2, RB>(nrb, acc_x, Xw, LD, Br, ld2, D, rot);
+            tile_mma_n<VAR, 2, RB>(nrb, acc_x, Xw, LD, Br, ld2, D, rot, nullptr, aoff);
         }
     }
     {   // da_z has been waiting in Y since the prologue
         const float* const Bz[2] = {Az_h, Az_h + 4 * D};
-        tile_mma_n<VAR, 2, RB>(nrb, acc_x, Yw, LD, Bz, ld2, D, rot);
+        tile_mma_n<VAR, 2, RB>(nrb, acc_x, Yw, LD, Bz, ld2, D, rot, nullptr, aoff);
     }
     FZ_GSYNC();                              // all waves of this half done with X and Y
     // ---- X <- dm ----
-    FZ_FOR_ACC { Xl[LOFF(rb, reg)] = acc_x[1][rb][reg]; }
+    FZ_FOR_ACC { Xs[FZ_ROWOF(rb, reg) * LD + col] = acc_x[1][rb][reg]; }
     __syncthreads();                         // whole workgroup: the transposed gather reads dm of every row of the tile
 
     // ---- message backward: G_e = gather^T_e(dm) ; dh += G_e . W_e^T ----
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         FZ_GATHER(Xs, Ys, e, &wd);
         if ((tid >> 2) < nrows) {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
             const int row = tid >> 2, q = tid & 3;
-            const float* s = Ys + row * LD + q * (D / 4);
+            const float* s = Ys + ((row & 64) + ro.inv[row]) * LD + q * (D / 4);       // (the gather put the row at its position)
             float* o = a.gda + (size_t)(row0 + row) * 7 * D + e * D + q * (D / 4);
 #pragma unroll
             for (int f = 0; f < D / 16; ++f) *(f32x4*)(o + 4 * f) = *(const f32x4*)(s + 4 * f);
@@ -352,11 +365,11 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
+        if (any) tile_mma_msg<VAR, 1, RB>(nrb, e, ro.nbr, bi, acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
-    // ---- dh = (MFMA part, via Y) + ex ----
-    FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
+    // ---- dh = (MFMA part, via Y: accumulator position -> row) + ex ----
+    FZ_FOR_ACC { Ys[FZ_ROWOF(rb, reg) * LD + col] = acc_h[0][rb][reg]; }
     FZ_GSYNC();
 #pragma unroll
     for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v) + ex[v]);
@@ -364,6 +377,7 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
 #undef RM_ROW
 #undef RM_C4
 #undef RM_LDS
+#undef FZ_ROWOF
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,6 +444,11 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
     const bool csr_lds = stage_csr(a.ptr, a.col, a.val, row0, rptr, ecol, evalv, nrows);
     __syncthreads();
     if (!grp_live) return;                   // a short tile: this half has no rows
+    const RowOrder ro = FZ_ROW_ORDER();      // the half's rows by (rare bond type, row): the order of this kernel's accumulators
+    const int bi = wr & 1;
+    int aoff[RB];                            // the self connection reads its h rows in that order too
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { const int tp = wrow0 + rb * 32 + l31; aoff[rb] = (((tp & 64) + ro.perm[tp]) - (wrow0 + l31)) * LD; }
 
     f32x16 acc[1][RB];
     zero_acc(acc[0]);
@@ -448,22 +467,23 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_fwd(RelArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc, Aw, LD, Bp, ldw, D, rot, &pre);
+        if (any) tile_mma_msg<VAR, 1, RB>(nrb, e, ro.nbr, bi, acc, Aw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
-    tile_mma_n<VAR, 1, RB>(nrb, acc, Hw, LD, Bs, lds_, D, rot, &pre_s);          // self connection: h . W_s^T
+    tile_mma_n<VAR, 1, RB>(nrb, acc, Hw, LD, Bs, lds_, D, rot, &pre_s, aoff);    // self connection: h . W_s^T
     {
-        const AccBuf oo = acc_buf<D>(a.out, row0, lrow, col);
+        const AccBuf oo = acc_buf<D>(a.out, row0, 0, col);
         float be[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) be[e] = a.bE[e * D + col];
         const float bsv = a.bs ? a.bs[col] : 0.f;
         const int act = a.act;
         FZ_FOR_ACC {
-            const int r = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+            const int tp = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);              // accumulator position ...
+            const int r = (tp & 64) + ro.perm[tp];                                    // ... -> row
             const f32x4 wd4 = *(const f32x4*)(wds + r * 4);
             const float v = acc[0][rb][reg] + bsv + wd4[0] * be[0] + wd4[1] * be[1] + wd4[2] * be[2] + wd4[3] * be[3];
-            acc_st<D>(oo, rb, reg, bmp_act(act, v));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bmp_act(act, v)), oo.rs, oo.vo + r * D * 4, 0, 0);
         }
     }
     if (a.wdeg != nullptr && (tid & 255) < 64 && grp * 64 + (tid & 255) < nrows) {   // this half's weighted degrees (written by this half's threads, group-synced
@@ -536,10 +556,15 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
     BPre<1> pre_s;
     tile_b_prefetch<1>(pre_s, Bs, lds_, D, rot);
     __syncthreads();
+    const RowOrder ro = FZ_ROW_ORDER();      // the half's rows by (rare bond type, row): the order of this kernel's accumulators
+    const int bi = wr & 1;
+    int aoff[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { const int tp = wrow0 + rb * 32 + l31; aoff[rb] = (((tp & 64) + ro.perm[tp]) - (wrow0 + l31)) * LD; }
 
     f32x16 acc_h[1][RB];
     zero_acc(acc_h[0]);
-    tile_mma_n<VAR, 1, RB>(nrb, acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s);        // dh = dpre . W_s
+    tile_mma_n<VAR, 1, RB>(nrb, acc_h, Xw, LD, Bs, lds_, D, rot, &pre_s, aoff);  // dh = dpre . W_s
     for (int e = 0; e < 4; ++e) {
         const float* const Bp[1] = {a.Wnat + (size_t)(4 * hi) * 4 * D + 4 * (e * D + col)};
         const int ldw[1] = {4 * D};
@@ -549,7 +574,7 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
         FZ_GATHER(Xs, Ys, e, &wd);
         if ((tid >> 2) < nrows) {
             const int row = tid >> 2, q = tid & 3;
-            const float* s = Ys + row * LD + q * (D / 4);
+            const float* s = Ys + ((row & 64) + ro.inv[row]) * LD + q * (D / 4);       // (the gather put the row at its position)
             float* o = a.gda + (size_t)(row0 + row) * 5 * D + e * D + q * (D / 4);
 #pragma unroll
             for (int f = 0; f < D / 16; ++f) *(f32x4*)(o + 4 * f) = *(const f32x4*)(s + 4 * f);
@@ -557,10 +582,13 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
         if (e == 0 && (tid & 3) == 0 && tmask) __hip_atomic_fetch_or(sy + 2 + grp, tmask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         grp_sync(gs);
         const int any = (__hip_atomic_load(sy + 2 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> e) & 1;
-        if (any) tile_mma_n<VAR, 1, RB>(nrb, acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
+        if (any) tile_mma_msg<VAR, 1, RB>(nrb, e, ro.nbr, bi, acc_h, Yw, LD, Bp, ldw, D, rot, &pre);
         FZ_GSYNC();
     }
-    FZ_FOR_ACC { Yl[LOFF(rb, reg)] = acc_h[0][rb][reg]; }
+    FZ_FOR_ACC {
+        const int tp = lrow + rb * 32 + (reg & 3) + 8 * (reg >> 2);
+        Ys[((tp & 64) + ro.perm[tp]) * LD + col] = acc_h[0][rb][reg];
+    }
     FZ_GSYNC();
 #pragma unroll
     for (int v = 0; v < NV; ++v) if (RM_LIVE(v)) rm_st<D, D>(b_dh, v, RM_LDS(Ys, v));

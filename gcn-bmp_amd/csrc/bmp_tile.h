@@ -62,9 +62,11 @@ __device__ __forceinline__ void tile_b_prefetch(BPre<NB>& p, const float* const 
 
 // NRB (<= RB): live row blocks of this wave (a short tile of the encoder layout); the other blocks' A loads and MFMAs do not
 // exist in that instance.
+// aoff (optional): float offset of row block rb's A rows from As_wave, per lane -- rows taken in another order than they lie
+// in the tile (the type-sorted order of a half, fz_row_order); null: block rb = rows + 32 rb.
 template <int NB, int RB, int NRB = RB>
 __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
+                                         const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr, const int* aoff = nullptr) {
     // B fragments run two k-steps ahead of the MFMAs (register ring b0 <- b1 <- b2); the load of step s+2 is
     // issued, and pinned by a scheduling barrier, BEFORE the MFMAs of step s, so an L2 round trip hides under
     // two steps of matrix work.  The loop wraps (k mod K), so the look-ahead loads are always in range.
@@ -81,13 +83,13 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
     }
     f32x4 a0[NRB], a1[NRB];          // A fragments (LDS) run one k-step ahead
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) a0[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k);
+    for (int rb = 0; rb < NRB; ++rb) a0[rb] = *(const f32x4*)(As_wave + (aoff ? aoff[rb] : rb * 32 * LD) + k);
     for (int it = 0; it < K; it += 8) {
         int k2 = k1 + 8; if (k2 >= K) k2 -= K;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) b2[nb] = *(const f32x4*)(Bp[nb] + (size_t)k2 * ldw[nb]);
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) a1[rb] = *(const f32x4*)(As_wave + rb * 32 * LD + k1);
+        for (int rb = 0; rb < NRB; ++rb) a1[rb] = *(const f32x4*)(As_wave + (aoff ? aoff[rb] : rb * 32 * LD) + k1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -107,14 +109,14 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[NB][RB], const float* As_
 // tile_mma for a wave with `nrb` live row blocks (0: nothing to do).  VAR == false: whole tiles, nrb == RB at compile time.
 template <bool VAR, int NB, int RB>
 __device__ __forceinline__ void tile_mma_n(int nrb, f32x16 (&acc)[NB][RB], const float* As_wave, int LD, const float* const (&Bp)[NB],
-                                           const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr) {
+                                           const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre = nullptr, const int* aoff = nullptr) {
     if constexpr (!VAR) {
-        tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+        tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre, aoff);
     } else if constexpr (RB == 1) {
-        if (nrb > 0) tile_mma<NB, 1, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+        if (nrb > 0) tile_mma<NB, 1, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre, aoff);
     } else {
-        if (nrb == RB) tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
-        else if (nrb > 0) tile_mma<NB, RB, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+        if (nrb == RB) tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre, aoff);
+        else if (nrb > 0) tile_mma<NB, RB, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre, aoff);
     }
 }
 
@@ -133,7 +135,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N]) {
 // arrays, or the copy of the tile's entries staged in LDS -- see stage_csr).
 template <int D>
 __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_tile, int LD, const int* ptr, const int* col,
-                                            const float* val, int row0, int e, float* wsum, int* tmask, int nrows = FZ_R) {
+                                            const float* val, int row0, int e, float* wsum, int* tmask, int nrows = FZ_R,
+                                            const unsigned char* inv = nullptr) {
     constexpr int F = D / 16;                 // float4 per thread
     const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
     f32x4 acc[F];
@@ -156,7 +159,8 @@ __device__ __forceinline__ bool tile_gather(const float* src_tile, float* dst_ti
             any = true;
         }
     }
-    float* o = dst_tile + row * LD + q * (D / 4);
+    // (inv: the row goes to its position in the half's type-sorted order, fz_row_order)
+    float* o = dst_tile + (inv ? (row & 64) + inv[row] : row) * LD + q * (D / 4);
 #pragma unroll
     for (int f = 0; f < F; ++f) *(f32x4*)(o + 4 * f) = acc[f];
     *wsum = wd;
@@ -175,8 +179,9 @@ __device__ __forceinline__ bool stage_csr(const int* ptr, const int* col, const 
     for (int i = threadIdx.x; i < ne; i += nt) { ecol[i] = col[ebase + i]; evalv[i] = val[ebase + i]; }
     return true;
 }
-#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp, &tmask, nrows) \
-                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp, &tmask, nrows))
+#define FZ_GATHER(srcT, dstT, e, wdp) (csr_lds ? tile_gather<D>(srcT, dstT, LD, rptr, ecol, evalv, row0, e, wdp, &tmask, nrows, ro.inv) \
+                                               : tile_gather<D>(srcT, dstT, LD, a.ptr + row0, a.col, a.val, row0, e, wdp, &tmask, nrows, ro.inv))
+#define FZ_ROW_ORDER() fz_row_order(sy, gs, grp, w, lane, csr_lds ? rptr : a.ptr + row0, csr_lds ? ecol : a.col, nrows)
 
 // ---- half-tile groups --------------------------------------------------------------------------------------
 // Waves 0-3 own rows [0, 64) of the tile and waves 4-7 rows [64, 128) in every phase (gather rows, MFMA A rows,
@@ -197,7 +202,62 @@ __device__ __forceinline__ void grp_sync(GrpSync& g) {
     while (__hip_atomic_load(g.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < g.target) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-#define FZ_NSYNC 8          // ints of LDS: ctr[2] at +0,+1 ; type masks [2] at +2,+3
+#define FZ_NSYNC 72         // ints of LDS: ctr[2] at +0,+1 ; type masks [2] at +2,+3 ; rare-row counts [2] at +4,+5 ;
+                            // row -> position [128 bytes] at +8 ; position -> row [128 bytes] at +40  (fz_row_order)
+
+// ---- type-sorted row order of a half tile, for the message phases (round 4) -------------------------------------
+// A row's gathered operand for bond type e (AGG_e forward, G_e backward) is zero unless the row has a bond of that type, and
+// double / triple bonds are rare: 19 % / 2 % of the rows, ~12 + 1 of a 64-row half tile -- yet with rows in their packed
+// order every 32-row MFMA block holds one, so both blocks of the half were multiplied for every type (the per-type skip
+// only fires when a type is absent from the whole half).  For the message phases the half's rows are therefore taken in the
+// order (has a double or triple bond, row): the rare types' rows fill the first positions and their MFMAs cover
+// ceil(count / 32) blocks -- one instead of two -- while the accumulators of all four types still line up (one order for
+// all).  The gather writes its operand rows at their positions, the MFMA loop is unchanged, and the one epilogue that
+// leaves the phase (m forward, dh backward) looks its rows up.  On the DDI batches: 5.5 instead of 6.9 blocks per half and
+// step, 7 % of the step kernels' MFMAs (measured as an upper bound by skipping the second block blindly: C2 +3.3 %, C3
+// +12 %).
+#define FZ_RARE_TYPES 0x6       // bit e: type e is a rare type (1 = double, 2 = triple)
+struct RowOrder {
+    const unsigned char* inv;   // [128] tile row -> position inside its half (0..63)
+    const unsigned char* perm;  // [128] half * 64 + position -> row inside the half
+    int nbr;                    // 32-row blocks of this half that hold rows with a rare bond type (0, 1 or 2)
+};
+// Called by every wave of a live group once the tile's CSR is visible; wave 4 g (one lane per row of the half) ranks the
+// rows; ends with the group's own sync.
+__device__ __forceinline__ RowOrder fz_row_order(int* sy, GrpSync& gs, int grp, int w, int lane, const int* ptr_local, const int* col,
+                                                 int nrows) {
+    unsigned char* inv = (unsigned char*)(sy + 8);
+    unsigned char* perm = (unsigned char*)(sy + 40);
+    if ((w & 3) == 0) {
+        const int r = grp * 64 + lane;
+        int m = 0;
+        if (r < nrows)
+            for (int ed = ptr_local[r]; ed < ptr_local[r + 1]; ++ed) m |= 1 << (col[ed] & 3);
+        const bool rare = (m & FZ_RARE_TYPES) != 0;
+        const unsigned long long bal = __ballot(rare), lt = (1ull << lane) - 1ull;
+        const int nr = __popcll(bal);
+        const int pos = rare ? __popcll(bal & lt) : nr + __popcll(~bal & lt);
+        inv[r] = (unsigned char)pos;
+        perm[grp * 64 + pos] = (unsigned char)lane;
+        if (lane == 0) sy[4 + grp] = nr;
+    }
+    grp_sync(gs);
+    return RowOrder{inv, perm, (sy[4 + grp] + 31) >> 5};
+}
+// MFMAs of one bond type's message product on this wave's rows: every live block, or -- a rare type -- the blocks that hold
+// its rows.  bi: the wave's block inside its half when RB == 1.
+template <bool VAR, int NB, int RB>
+__device__ __forceinline__ void tile_mma_msg(int nrb, int e, int nbr, int bi, f32x16 (&acc)[NB][RB], const float* As_wave, int LD,
+                                             const float* const (&Bp)[NB], const int (&ldw)[NB], int K, int rot, const BPre<NB>* pre) {
+    const bool rare = (FZ_RARE_TYPES >> e) & 1;
+    if constexpr (RB == 1) {
+        if (nrb > 0 && (!rare || bi < nbr)) tile_mma<NB, 1, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+    } else {
+        const int nb = rare ? (nbr < nrb ? nbr : nrb) : nrb;
+        if (nb >= RB) tile_mma<NB, RB, RB>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+        else if (nb > 0) tile_mma<NB, RB, 1>(acc, As_wave, LD, Bp, ldw, K, rot, pre);
+    }
+}
 
 // Accumulator-layout access to a row-major [rows x LDC] f32 array through a buffer resource: all 16*RB
 // positions of a wave share ONE 32-bit voffset VGPR (the lane's (row, col) byte offset); the per-register
