@@ -459,6 +459,7 @@ def main():
                 pb, t = env.collate(*state["p"], i, B=state["B"], layout=state.get("layout"))
                 host_ms.append(time.perf_counter() - t0)
                 env.train_step(pb, t)
+                state["host_s"] = state.get("host_s", 0.0) + (time.perf_counter() - t0)
             return body
         st = dict(epoch=0, B=PAIRS_PER_GPU)
         body = epoch_body(st)
@@ -491,14 +492,17 @@ def main():
             if args.host_profile:
                 prof = cProfile.Profile()
                 prof.enable()
+            st["host_s"] = 0.0
             dt_32, _ = timed(n32, lambda i: body(i + 1))
             if args.host_profile:
                 prof.disable()
                 pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
             b32 = dict(value=round(32 * n32 / dt_32, 1), unit="pairs/s", steps=n32, ms_per_step=round(1e3 * dt_32 / n32, 3),
-                       layout=st["layout"] or LAYOUT,
+                       host_ms_per_step=round(1e3 * st["host_s"] / n32, 3), layout=st["layout"] or LAYOUT,
                        what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end; the "
-                            "encoder layout gives every molecule a tile of its own height, spread over the CUs")
+                            "encoder layout gives every molecule a tile of its own height, spread over the CUs; host_ms_per_step = time the "
+                            "host spends inside a step's calls (collate + ~55 launches through the framework's autograd): when it equals "
+                            "ms_per_step the leg measures the host, not the GPU path")
         if world == 1:
             # ---- forward-only leg: the evaluation callers' predict (eval_coattention.py:103-124; the evaluator extensions run
             #      it over the train and validation sets every epoch, training/extensions/batch_evaluator.py:49-100) ----

@@ -327,13 +327,24 @@ __device__ __forceinline__ void rowgemm_lds_body(const RGArgs& a, int bx, int by
 #define RGD_A_FLOATS (128 * RGD_LDA)
 #define RGD_B_FLOATS (8 * 128 * 4)
 #define RGD_SWZ(n) ((n) ^ (((n) >> 4) & 3))
-template <int EPI>
-__device__ __forceinline__ void rowgemm_db_body(const RGArgs& a, int bx, int by, float* lds) {
+// LISTED: the tile's 128 rows are the list entries [128 bx, 128 bx + 128) (a.ridx; *a.rcnt of them exist): A rows and Y rows go
+// through `rows` (LDS, 128 ints), entries past the end re-read the last row and store nothing.
+template <int EPI, bool LISTED = false>
+__device__ __forceinline__ void rowgemm_db_body(const RGArgs& a, int bx, int by, float* lds, int* rows = nullptr) {
     constexpr int RB = 4, R = 128, NT = 128;
     constexpr int BUF = RGD_A_FLOATS + RGD_B_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int row0 = bx * R, n0 = by * NT;
+    int count = 0x7fffffff;
+    int xrow[4] = {0, 0, 0, 0};              // LISTED: the four A rows this thread stages (rows (tid >> 3) + 32 it of the tile)
+    if (LISTED) {
+        count = a.rcnt[0];
+        if (row0 >= count) return;
+        if (tid < R) { const int p = row0 + tid; rows[tid] = a.ridx[p < count ? p : count - 1]; }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { const int p = row0 + (tid >> 3) + 32 * it; xrow[it] = a.ridx[p < count ? p : count - 1]; }
+    }
 
     f32x16 acc[RB];
 #pragma unroll
@@ -354,10 +365,11 @@ __device__ __forceinline__ void rowgemm_db_body(const RGArgs& a, int bx, int by,
         for (int it = 0; it < 4; ++it) {
             const int idx = tid + it * 256;
             const int r = idx >> 3, c4 = idx & 7;
+            const size_t grow = LISTED ? (size_t)xrow[it] : (size_t)(row0 + r);
             f32x4 v = zero4;
             if (4 * c4 < kc) {
-                v = *(const f32x4*)(X + (size_t)(row0 + r) * ldx + k0_ + 4 * c4);
-                if (X2) v *= *(const f32x4*)(X2 + (size_t)(row0 + r) * ldx2 + k0_ + 4 * c4);
+                v = *(const f32x4*)(X + grow * ldx + k0_ + 4 * c4);
+                if (X2) v *= *(const f32x4*)(X2 + grow * ldx2 + k0_ + 4 * c4);
             }
             sa[it] = v;
         }
@@ -424,8 +436,9 @@ __device__ __forceinline__ void rowgemm_db_body(const RGArgs& a, int bx, int by,
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = row0 + rb * 32 + bmp_acc_row(reg, lane);
-                rg_epilogue<EPI>(a, cc, row, col, acc[rb][reg]);
+                const int lr = rb * 32 + bmp_acc_row(reg, lane);
+                if (LISTED) { if (row0 + lr < count) rg_epilogue<EPI>(a, cc, rows[lr], col, acc[rb][reg]); }
+                else rg_epilogue<EPI>(a, cc, row0 + lr, col, acc[rb][reg]);
             }
     }
 }
@@ -434,6 +447,12 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm_db(RGArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (RGD_A_FLOATS + RGD_B_FLOATS)];
     rowgemm_db_body<EPI>(a, blockIdx.x, blockIdx.y, lds);      // (column tiles fastest in the grid: 1.5 % slower on C4)
+}
+// rows through a list (generic epilogue): the per-bond-type blocks of the unfused message operator's backward
+__global__ __launch_bounds__(256) void k_rowgemm_db_listed(RGArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (RGD_A_FLOATS + RGD_B_FLOATS)];
+    __shared__ int rows[128];
+    rowgemm_db_body<BMP_EPI_GENERIC, true>(a, blockIdx.x, blockIdx.y, lds, rows);
 }
 
 template <int EPI>
@@ -505,6 +524,21 @@ int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st) {
         case BMP_EPI_GRU_DRH: return launch_rowgemm_epi<BMP_EPI_GRU_DRH>(a, n_tiles, st);
     }
     return -1;
+}
+
+int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st) {
+    BMP_REQUIRE(n_tiles_cap > 0 && a.Nout > 0 && a.nsrc >= 1 && a.nsrc <= 3 && a.ridx && a.rcnt && rowgemm_lds_ok(a));
+    double ksum = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        BMP_REQUIRE(a.s[s].K > 0 && (a.s[s].K & 7) == 0 && (a.s[s].ldx & 3) == 0 && ((uintptr_t)a.s[s].X & 15) == 0 && !a.s[s].X2);
+        ksum += a.s[s].K;
+    }
+    // (flop accounting: the listed share is not known on the host; the roofline leg's algorithmic figure counts every row)
+    const double rows = (double)n_tiles_cap * BMP_R;
+    BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * ksum * a.Nout, 4.0 * rows * (ksum + a.Nout), st);
+    hipLaunchKernelGGL(k_rowgemm_db_listed, dim3(n_tiles_cap, (a.Nout + 127) / 128), dim3(256), 0, st, a);
+    BMP_LAUNCH_CHECK();
+    return 0;
 }
 
 int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStream_t st) {

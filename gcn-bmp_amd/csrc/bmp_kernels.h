@@ -37,6 +37,10 @@ struct RGArgs {
     int act_lo, act_hi;              // activation below / at-or-above split (act_lo everywhere if no split)
     float* o1; int ldo1;             // columns >= split go to o1[row, col - split] when o1 != nullptr
     int accumulate;                  // Y += instead of Y =
+    // row LIST (round 4; bmp_launch_rowgemm_listed): the launch computes the rows ridx[0 .. *rcnt) only -- A rows and Y rows are
+    // both taken through the list (device arrays; tiles past the end of the list exit) -- for the per-bond-type blocks of the
+    // unfused message operator's backward, whose other rows nobody reads.
+    const int* ridx; const int* rcnt;
     // GRU extras
     const float* z; int ldz;
     const float* h; int ldh;
@@ -46,6 +50,8 @@ struct RGArgs {
 };
 
 int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st);
+// generic epilogue, rows through a.ridx / a.rcnt; n_tiles_cap: tiles of the longest possible list (all rows)
+int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st);
 // n <= 3 independent problems (generic epilogue) in ONE launch
 int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStream_t st);
 
