@@ -504,16 +504,31 @@ template <int D>
 __global__ __launch_bounds__(256) void k_step_wgrad_fold_s(const float* __restrict__ ws, int G, int first, int accumulate,
                                                            float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ dUcT,
                                                            float* __restrict__ cs) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= FSW_PART(D)) return;
-    float* dst; bool live = true;
-    if (idx < D * 7 * D) { const int c = idx % (7 * D); dst = o1 + idx; live = !(first && c >= 4 * D && c < 5 * D); }
-    else if (idx < D * 10 * D) { const int k = idx - D * 7 * D; dst = o2 + k; live = !(first && (k % (3 * D)) < D); }
-    else if (idx < D * 11 * D) { dst = dUcT + (idx - D * 10 * D); live = !first; }
-    else { const int c = idx - D * 11 * D; dst = cs + c; live = !(first && c >= 4 * D && c < 5 * D); }
+    // 64 output elements per workgroup, four lanes of partial sums each (partials g, g + 4, ...), joined in a fixed order: a
+    // quarter of the dependent chain of one thread per element walking all G partials (that form: 60 us per launch, more than
+    // the products' kernel)
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + c;
+    float* dst = nullptr; bool live = false;
+    if (idx < FSW_PART(D)) {
+        live = true;
+        if (idx < D * 7 * D) { const int col = idx % (7 * D); dst = o1 + idx; live = !(first && col >= 4 * D && col < 5 * D); }
+        else if (idx < D * 10 * D) { const int k = idx - D * 7 * D; dst = o2 + k; live = !(first && (k % (3 * D)) < D); }
+        else if (idx < D * 11 * D) { dst = dUcT + (idx - D * 10 * D); live = !first; }
+        else { const int col = idx - D * 11 * D; dst = cs + col; live = !(first && col >= 4 * D && col < 5 * D); }
+    }
     float acc = 0.f;
-    if (live) for (int g = 0; g < G; ++g) acc += ws[(size_t)g * FSW_PART(D) + idx];
-    *dst = accumulate ? *dst + acc : acc;
+    if (live) {
+#pragma unroll 8
+        for (int g = q; g < G; g += 4) acc += ws[(size_t)g * FSW_PART(D) + idx];
+    }
+    red[q][c] = acc;
+    __syncthreads();
+    if (q == 0 && dst != nullptr) {
+        const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        *dst = accumulate ? *dst + v : v;
+    }
 }
 
 static void fsw_plan(int N, int& G, int& rps) {
@@ -533,7 +548,7 @@ int bmp_launch_step_wgrad_small(const float* h, const float* m, const float* rz,
     if (first) hipLaunchKernelGGL((k_step_wgrad_s<32, true>), dim3(G), dim3(256), 0, st, h, m, rz, gda, N, rps, ws);
     else hipLaunchKernelGGL((k_step_wgrad_s<32, false>), dim3(G), dim3(256), 0, st, h, m, rz, gda, N, rps, ws);
     BMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_step_wgrad_fold_s<32>), dim3((FSW_PART(32) + 255) / 256), dim3(256), 0, st, ws, G, first, accumulate, o1, o2, dUcT, cs);
+    hipLaunchKernelGGL((k_step_wgrad_fold_s<32>), dim3((FSW_PART(32) + 63) / 64), dim3(256), 0, st, ws, G, first, accumulate, o1, o2, dUcT, cs);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void k_pf_ntn_bwd_w(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < MAXO; ++t) accW[t] = 0.f;
     float accV1 = 0.f, accV2 = 0.f, accB = 0.f;
+    const bool small = nW > 0 && nW <= 128;          // (uniform per workgroup)
     for (int b0 = 0; b0 < B; b0 += PF_WR) {
         const int nr = B - b0 < PF_WR ? B - b0 : PF_WR;
         __syncthreads();
@@ -220,6 +221,15 @@ __global__ __launch_bounds__(256) void k_pf_ntn_bwd_w(const float* __restrict__ 
         for (int i = tid; i < nr * d2; i += 256) sx2[i] = x2[(size_t)b0 * d2 + i];
         for (int i = tid; i < nr * K; i += 256) sg[i] = g[(size_t)b0 * K + i];
         __syncthreads();
+        if (small) {          // at most 128 outputs: the two halves of the workgroup take the chunk's even / odd rows
+            const int idx = tid & 127, g = tid >> 7;
+            if (idx < nW) {
+                const int q = idx / K, o = idx % K;
+                float acc = accW[0];
+                for (int b = g; b < nr; b += 2) acc += sx1[b] * sx2[b * d2 + q] * sg[b * K + o];
+                accW[0] = acc;
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < MAXO; ++t) {
             const int idx = tid + 256 * t;
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256) void k_pf_ntn_bwd_w(const float* __restrict__ 
                 accW[t] = acc;
             }
         }
+        }
         if (tid < K) {
             const int o = tid;
             if (dV1 && p < d1) for (int b = 0; b < nr; ++b) accV1 += sx1[b] * sg[b * K + o];
@@ -237,10 +248,17 @@ __global__ __launch_bounds__(256) void k_pf_ntn_bwd_w(const float* __restrict__ 
             if (db && p == 0) for (int b = 0; b < nr; ++b) accB += sg[b * K + o];
         }
     }
+    if (small) {              // even-row sums + odd-row sums, through LDS (the staging area is free by now)
+        __syncthreads();
+        if (tid >= 128) pf_lds[tid - 128] = accW[0];
+        __syncthreads();
+        if (tid < nW) dW[(size_t)p * d2 * K + tid] = accW[0] + pf_lds[tid];
+    } else {
 #pragma unroll
     for (int t = 0; t < MAXO; ++t) {
         const int idx = tid + 256 * t;
         if (idx < nW) dW[(size_t)p * d2 * K + idx] = accW[t];
+    }
     }
     if (tid < K) {
         if (dV1 && p < d1) dV1[(size_t)p * K + tid] = accV1;
@@ -309,7 +327,7 @@ extern "C" int bmp_pairfeat_bwd(int kind, const float* dout, const float* x1, co
             hipLaunchKernelGGL(k_pf_ntn_bwd_x, dim3((B + PF_RB - 1) / PF_RB), dim3(256), 0, st, dout, x1, x2, B, d1, d2, W, V1, V2, K, dx1, dx2);
             BMP_LAUNCH_CHECK();
             const int nb = d1 > d2 ? d1 : d2;
-            hipLaunchKernelGGL(k_pf_ntn_bwd_w, dim3(nb), dim3(256), (size_t)PF_WR * (1 + d2 + K) * sizeof(float), st, dout, x1, x2, B, d1, d2,
+            hipLaunchKernelGGL(k_pf_ntn_bwd_w, dim3(nb), dim3(256), (size_t)(PF_WR * (1 + d2 + K) > 128 ? PF_WR * (1 + d2 + K) : 128) * sizeof(float), st, dout, x1, x2, B, d1, d2,
                                K, dW, dV1, dV2, db);
             break;
         }
