@@ -526,6 +526,8 @@ int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st) {
     return -1;
 }
 
+bool bmp_rowgemm_listed_ok(const RGArgs& a) { return a.ridx && a.rcnt && rowgemm_lds_ok(a); }
+
 int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st) {
     BMP_REQUIRE(n_tiles_cap > 0 && a.Nout > 0 && a.nsrc >= 1 && a.nsrc <= 3 && a.ridx && a.rcnt && rowgemm_lds_ok(a));
     double ksum = 0;

@@ -52,6 +52,7 @@ struct RGArgs {
 int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st);
 // generic epilogue, rows through a.ridx / a.rcnt; n_tiles_cap: tiles of the longest possible list (all rows)
 int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st);
+bool bmp_rowgemm_listed_ok(const RGArgs& a);      // the listed form exists for the LDS-staged kernel only (weight alignment; BMP_ROWGEMM_DIRECT unset)
 // n <= 3 independent problems (generic epilogue) in ONE launch
 int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStream_t st);
 

@@ -176,8 +176,15 @@ extern "C" int bmp_msg_bwd(const float* dout, int lddo, const float* out, int ld
     // listed rows (1.46 N instead of 4 N row blocks on the DDI batches); the blocks that are not computed are not read.
     // (The forward product out = sum_e agg_e . W_e was tried the same way -- out cleared, four listed launches adding to their
     //  rows -- and lost 5 % of the C4 step to the read-modify-write of out and to its four part-filled launches per chain.)
-    if (type_rows_f && type_cnt_f && (d_in & 3) == 0 && ((uintptr_t)Wnat & 15) == 0 && ((uintptr_t)dpre & 15) == 0 && (lddp & 3) == 0 &&
-        n_tiles >= 64) {
+    bool listed = type_rows_f && type_cnt_f && (d_in & 3) == 0 && ((uintptr_t)Wnat & 15) == 0 && ((uintptr_t)dpre & 15) == 0 &&
+                  (lddp & 3) == 0 && n_tiles >= 64;
+    if (listed) {
+        RGArgs a = rg_zero();
+        a.s[0] = RGSrc{dpre, nullptr, Wnat, lddp, 0, 4 * d_in, d_out};
+        a.nsrc = 1; a.Nout = d_in; a.ridx = type_rows_f; a.rcnt = type_cnt_f;
+        listed = bmp_rowgemm_listed_ok(a);
+    }
+    if (listed) {
         for (int e = 0; e < 4; ++e) {
             RGArgs a = rg_zero();
             a.s[0] = RGSrc{dpre, nullptr, Wnat + e * d_in, lddp, 0, 4 * d_in, d_out};
