@@ -21,7 +21,10 @@ def golden_dir():
 def pytest_collection_finish(session):
     # achieved-error log of tests/parity_util.py: a fresh file for every session that RUNS gpu-marked tests; a CPU-only
     # session (-m "not gpu") logs nothing and must leave the last GPU session's log and summary alone
-    session.config._bmp_gpu_session = any(it.get_closest_marker("gpu") is not None for it in session.items)
+    # (a test may start a child pytest session -- tests/test_gpu_type_rows.py --: the child appends to the parent's log and
+    #  leaves rotation and summary to the parent: BMP_PARITY_CHILD=1)
+    session.config._bmp_gpu_session = (any(it.get_closest_marker("gpu") is not None for it in session.items)
+                                       and os.environ.get("BMP_PARITY_CHILD") != "1")
     if session.config._bmp_gpu_session:
         for name in ("parity_errors.jsonl", "parity_summary.json"):
             try:

@@ -90,6 +90,6 @@ def test_lists_off_switch_reaches_the_library():
             "assert Fn._WGRAD_LISTS is False and Fn.type_rows(None) == (None, None)\n"
             "import pytest; sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', %r, '-k', 'fused_step_fwd_bwd and 128']))\n"
             % (ROOT, os.path.join(ROOT, "gcn-bmp_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "test_gpu_ops.py")))
-    env = dict(os.environ, BMP_WGRAD_LISTS="0")
+    env = dict(os.environ, BMP_WGRAD_LISTS="0", BMP_PARITY_CHILD="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
