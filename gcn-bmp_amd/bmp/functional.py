@@ -213,6 +213,16 @@ def type_rows(pb, forward: bool = False):
     return tr if tr is not None else (None, None)
 
 
+def step_lists(pb, N: int, d: int):
+    """(idx, cnt, skip) for a fused step / layer backward: the batch's transposed-CSR row lists when the weight-gradient launch
+    will read gda's per-type blocks through them (bmp_step_wgrad_lists_used) -- the backward tile kernel then skips the
+    blocks of rows without a bond of the type (skip = 1) --, else (None, None, 0)."""
+    tri, trc = type_rows(pb)
+    if tri is None or not _lib.lib().bmp_step_wgrad_lists_used(int(N), int(d)):
+        return None, None, 0
+    return tri, trc, 1
+
+
 def step_supported(d: int) -> bool:
     return bool(_lib.lib().bmp_ggnn_step_supported(int(d)))
 
@@ -224,12 +234,16 @@ def pack_k4(W: torch.Tensor) -> torch.Tensor:
     return W.detach().reshape(K // 4, 4, N).permute(0, 2, 1).contiguous()
 
 
-def _cached(cache, key, make):
+def _cached(cache, tag, src, make):
+    """The packed copy of ``src`` in the per-call ``cache``, keyed by the storage address.  The entry holds ``src`` itself:
+    under no_grad nothing else keeps a per-step weight tensor alive, and a freed block handed to the next layer's weights
+    would otherwise answer with the previous layer's packed copy."""
     if cache is None:
         return make()
+    key = (tag, src.data_ptr())
     if key not in cache:
-        cache[key] = make()
-    return cache[key]
+        cache[key] = (make(), src)
+    return cache[key][0]
 
 
 class GGNNStepFn(Function):
@@ -247,9 +261,9 @@ class GGNNStepFn(Function):
                 or tuple(UcT.shape) != (d, d) or tuple(b.shape) != (3 * d,):
             raise ValueError("step: weight shapes do not match h")
         bE, b = bE.contiguous(), b.contiguous()
-        WTp = _cached(cache, ("f", WT.data_ptr()), lambda: pack_k4(WT))
-        ATp = _cached(cache, ("f", AT.data_ptr()), lambda: pack_k4(AT))
-        UcTp = _cached(cache, ("f", UcT.data_ptr()), lambda: pack_k4(UcT))
+        WTp = _cached(cache, "f", WT, lambda: pack_k4(WT))
+        ATp = _cached(cache, "f", AT, lambda: pack_k4(AT))
+        UcTp = _cached(cache, "f", UcT, lambda: pack_k4(UcT))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=h.device)
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
         check(L.bmp_ggnn_step_fwd(ptr(h), 0, pb.n_mtiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
@@ -270,14 +284,15 @@ class GGNNStepFn(Function):
         N, d = h.shape
         dev = h.device
         dhout = dhout.contiguous()
-        Wnat = _cached(cache, ("b", WT.data_ptr()), lambda: pack_k4(WT.t()))
-        A = _cached(cache, ("b", AT.data_ptr()), lambda: pack_k4(AT.t()))
-        Uc = _cached(cache, ("b", UcT.data_ptr()), lambda: pack_k4(UcT.t()))
+        Wnat = _cached(cache, "b", WT, lambda: pack_k4(WT.t()))
+        A = _cached(cache, "b", AT, lambda: pack_k4(AT.t()))
+        Uc = _cached(cache, "b", UcT, lambda: pack_k4(UcT.t()))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         dh, gda = f(N, d), f(N, 7 * d)
+        tri, trc, skip = step_lists(pb, N, d)
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(A), ptr(Uc), ptr(dh), ptr(gda),
-                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()), "bmp_ggnn_step_bwd")
+                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()), "bmp_ggnn_step_bwd")
         # Steps that share BOTH weight sets (tied layers) accumulate their weight gradients in one set of
         # buffers inside the kernels; only the last of them to run hands the sums to autograd.
         grp = ("g", WT.data_ptr(), AT.data_ptr())
@@ -293,7 +308,6 @@ class GGNNStepFn(Function):
         acc = 1 if (st is not None and st["seen"] > 0) else 0
         nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
         ws = _ws(nws, dev)
-        tri, trc = type_rows(pb)
         check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(o1), ptr(o2), ptr(dUcT), ptr(cs),
                                     acc, ptr(tri), ptr(trc), ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
         if st is not None:
@@ -643,12 +657,11 @@ class PStepFn(Function):
         dhout = dhout.contiguous()
         dh = torch.empty(N, d, dtype=torch.float32, device=h.device)
         gda = torch.empty(N, 7 * d, dtype=torch.float32, device=h.device)
+        tri, trc, skip = step_lists(pb, N, d)
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
-                                  ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()), "bmp_ggnn_step_bwd")
+                                  ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()), "bmp_ggnn_step_bwd")
         acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
-
-        tri, trc = type_rows(pb)
 
         def wgrad(st, ws_of):
             nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
@@ -721,7 +734,7 @@ class PTStepsFn(Function):
         bufs = [sv[1 + 4 * t: 5 + 4 * t] for t in range(T)]
         N, d = h0.shape
         dh = dhout.contiguous()
-        tri, trc = type_rows(pb)
+        tri, trc, skip = step_lists(pb, N, d)
         for t in range(T - 1, -1, -1):
             W, G, gkey, first = steps[t]
             m, rz, c, _hout = bufs[t]
@@ -730,7 +743,7 @@ class PTStepsFn(Function):
             gda = torch.empty(N, 7 * d, dtype=torch.float32, device=h0.device)
             check(L.bmp_ggnn_step_bwd(ptr(dh), ptr(h_in), ptr(rz), ptr(c), pb.n_mtiles, d, int(first), ptr(pb.csrT_ptr),
                                       ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
-                                      ptr(dprev), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()), "bmp_ggnn_step_bwd")
+                                      ptr(dprev), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()), "bmp_ggnn_step_bwd")
             acc = 0 if _first_write(ctx.state, gkey) else 1
 
             def wgrad(st, ws_of, h_in=h_in, m=m, rz=rz, gda=gda, G=G, first=first, acc=acc):
@@ -944,11 +957,10 @@ def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate,
     N, d = x.shape
     dx = torch.empty(N, d, dtype=torch.float32, device=x.device)
     gda = torch.empty(N, 5 * d, dtype=torch.float32, device=x.device)
+    tri, trc, skip = step_lists(pb, N, d)
     check(L.bmp_relgcn_layer_bwd(ptr(dout), ptr(out), act, pb.n_mtiles, d, ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val),
-                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()),
+                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()),
               "bmp_relgcn_layer_bwd")
-
-    tri, trc = type_rows(pb)
 
     def wgrad(st, ws_of):
         nws = L.bmp_relgcn_layer_wgrad_ws_floats(N, d)

@@ -354,8 +354,8 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
         BPre<1> pre;
         tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
         float wd;
-        FZ_GATHER(Xs, Ys, e, &wd);
-        if ((tid >> 2) < nrows) {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
+        const bool has_e = FZ_GATHER(Xs, Ys, e, &wd);
+        if ((tid >> 2) < nrows && (has_e || !a.skip_zero_g)) {   // G_e -> HBM for the weight-gradient GEMM (row-wise, 16-byte stores)
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + ((row & 64) + ro.inv[row]) * LD + q * (D / 4);       // (the gather put the row at its position)
             float* o = a.gda + (size_t)(row0 + row) * 7 * D + e * D + q * (D / 4);
@@ -406,6 +406,7 @@ struct RelArgs {
     const float* Ws;                // [D x D]   (= WsT^T) K4-packed
     float* dh;
     float* gda;                     // [N x 5D]: G_0..G_3 (transposed gather of dpre per bond type) | dpre
+    int skip_zero_g;                // the G_e block of a row without a bond of type e (an exact zero) is not written
 };
 
 template <int D, bool VAR>
@@ -571,8 +572,8 @@ __global__ __launch_bounds__(512) void k_relgcn_layer_bwd(RelArgs a) {
         BPre<1> pre;
         tile_b_prefetch<1>(pre, Bp, ldw, D, rot);
         float wd;
-        FZ_GATHER(Xs, Ys, e, &wd);
-        if ((tid >> 2) < nrows) {
+        const bool has_e = FZ_GATHER(Xs, Ys, e, &wd);
+        if ((tid >> 2) < nrows && (has_e || !a.skip_zero_g)) {
             const int row = tid >> 2, q = tid & 3;
             const float* s = Ys + ((row & 64) + ro.inv[row]) * LD + q * (D / 4);       // (the gather put the row at its position)
             float* o = a.gda + (size_t)(row0 + row) * 5 * D + e * D + q * (D / 4);
@@ -801,14 +802,18 @@ extern "C" int bmp_ggnn_steps_fwd(const float* h, int tile0, int n_tiles, int d,
 
 // Backward-data of one step: dh (gradient w.r.t. the step input h) and gda [N x 7d] =
 // [G_0..G_3 | da_r | da_z | da_c] for bmp_ggnn_step_wgrad.  Wnat [d x 4d], A [3d x 2d], Uc [d x d].
+// skip_zero_g != 0: the caller reads gda's per-type blocks through the batch's row lists only (bmp_ggnn_step_wgrad with
+// type_rows, when bmp_step_wgrad_lists_used): the block G_e of a row WITHOUT a bond of type e -- an exact zero, 64 % of the
+// blocks of a DDI batch -- is then not written (77 of the 244 MB this launch stores: -4.5 % of its time, -11 % for a RelGCN layer).
 extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d,
                                  int first, const int* csrT_ptr, const int* csrT_col, const float* csrT_val,
                                  const float* Wnat, const float* A, const float* Uc, float* dh, float* gda,
-                                 const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
+                                 const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     StepArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
+    a.skip_zero_g = skip_zero_g && fz_wide(d);
     if (!fz_wide(d)) return bmp_launch_step_small(true, a, n_tiles, d, st);
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);
 }
@@ -846,6 +851,12 @@ static int step_wgrad_problems(WGArgs* g, const float* h, const float* m, const 
 }
 
 static bool step_wgrad_fusable(int N, int d) { return (d == 64 || d == 128) && (N & 31) == 0; }
+// Will bmp_ggnn_step_wgrad / bmp_relgcn_layer_wgrad, handed row lists, read gda's per-type blocks through them (and through
+// them only)?  The caller's licence for skip_zero_g of the backward launches.
+extern "C" int bmp_step_wgrad_lists_used(int N, int d) {
+    static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;
+    return !unfused && step_wgrad_fusable(N, d) && bmp_wgrad_fused_lists_ok(N);
+}
 
 extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
     size_t a = bmp_wgrad_ws_floats(N, d, 7 * d);
@@ -940,11 +951,11 @@ extern "C" int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int 
 // dh and gda [N x 5d] = [G_0..G_3 | dpre] for bmp_relgcn_layer_wgrad.  Wnat [d x 4d] = WT^T, Ws [d x d] = WsT^T, K4-packed.
 extern "C" int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                                     const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
-                                    float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
+                                    float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && fz_wide(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     RelArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.act = act; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
-    a.dout = dout; a.y = out; a.Wnat = Wnat; a.Ws = Ws; a.dh = dh; a.gda = gda;
+    a.dout = dout; a.y = out; a.Wnat = Wnat; a.Ws = Ws; a.dh = dh; a.gda = gda; a.skip_zero_g = skip_zero_g;
     return d == 128 ? rel_launch<128>(true, a, n_tiles, st) : rel_launch<64>(true, a, n_tiles, st);
 }
 

@@ -36,6 +36,7 @@ struct StepArgs {
     float* gda;                     // [N x 7D]: G (4D: gathered dm per bond type) | da_r | da_z | da_c
     // all T steps of a tile in one forward launch (k_ggnn_step_fwd<.., TS = true>): step t's weights and outputs
     int T;
+    int skip_zero_g;
     const float* ts_WT[FZ_TMAX]; const float* ts_bE[FZ_TMAX]; const float* ts_AT[FZ_TMAX]; const float* ts_b[FZ_TMAX];
     float* ts_m[FZ_TMAX]; float* ts_rz[FZ_TMAX]; float* ts_c[FZ_TMAX]; float* ts_hout[FZ_TMAX];
 };

@@ -146,7 +146,12 @@ int bmp_ggnn_steps_fwd(const float* h, int tile0, int n_tiles, int d, int T, int
                        float* const* hout, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
 int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
                       const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
-                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
+                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g,
+                      bmp_stream_t stream);
+/* skip_zero_g != 0 (bmp_ggnn_step_bwd, bmp_relgcn_layer_bwd): the caller reads gda's per-type blocks through the batch's row lists
+ * only -- it passes type_rows to the wgrad call and bmp_step_wgrad_lists_used(N, d) said the lists will be used -- so the block
+ * of a row without a bond of the type, an exact zero, is not written. */
+int bmp_step_wgrad_lists_used(int N, int d);
 size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
 /* type_rows [4 x N] / type_cnt [4] (both optional, NULL together): bmp_type_rows of the batch's TRANSPOSED CSR.  A row's
  * gathered gradient G_e is an exact zero unless the row has a bond of type e (73 / 19 / 2 / 52 % of the rows of a DDI batch for
@@ -175,7 +180,7 @@ int bmp_relgcn_layer_fwd(const float* h, int tile0, int n_tiles, int d, const in
                          float* wdeg, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);   /* wdeg may be NULL */
 int bmp_relgcn_layer_bwd(const float* dout, const float* out, int act, int n_tiles, int d, const int* csrT_ptr,
                          const int* csrT_col, const float* csrT_val, const float* Wnat, const float* Ws, float* dh,
-                         float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
+                         float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g, bmp_stream_t stream);
 size_t bmp_relgcn_layer_wgrad_ws_floats(int N, int d);
 int bmp_relgcn_layer_wgrad(const float* h, const float* wdeg, const float* gda, int N, int d, float* o1, float* dbE,
                            float* cs, int accumulate, const int* type_rows, const int* type_cnt, float* ws, size_t ws_floats,

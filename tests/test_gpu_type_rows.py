@@ -93,3 +93,41 @@ def test_lists_off_switch_reaches_the_library():
     env = dict(os.environ, BMP_WGRAD_LISTS="0", BMP_PARITY_CHILD="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("encoder", ["ggnn", "relgcn"])
+def test_backward_that_skips_zero_blocks_equals_the_one_that_writes_them(encoder):
+    """With the row lists on, the backward tile kernels do not write the G_e block of a row without a bond of type e
+    (skip_zero_g) and the weight-gradient launch reads those blocks through the lists only.  The same encoder step by step with
+    the lists switched off (every block written, every row read) must give the same gradients -- also when the memory the
+    unwritten blocks land in is full of NaNs."""
+    from bmp import functional as Fn
+    from bmp.ggnn import GGNN
+    from bmp.relgcn import RelGCN
+    from parity_util import close
+    pb = _batch(160, seed=9)
+    dev = pb.device
+    d = 128
+    assert Fn._lib.lib().bmp_step_wgrad_lists_used(pb.n_rows, d) == 1
+    torch.manual_seed(5)
+    enc = (GGNN(out_dim=d, hidden_dim=d, n_layers=3) if encoder == "ggnn" else RelGCN(out_channels=d, ch_list=[d] * 4, scale_adj=True)).to(dev)
+    cw = torch.randn(pb.n_mols, d, device=dev)
+    res = []
+    saved = Fn._WGRAD_LISTS
+    try:
+        for lists in (True, False):
+            Fn._WGRAD_LISTS = lists
+            enc.zero_grad()
+            poison = torch.full((pb.n_rows, 7 * d), float("nan"), device=dev)        # what torch.empty hands out next
+            del poison
+            g = enc(pb)
+            (g * cw).sum().backward()
+            torch.cuda.synchronize()
+            res.append({n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
+    finally:
+        Fn._WGRAD_LISTS = saved
+    assert res[0].keys() == res[1].keys() and len(res[0]) > 4
+    for n in res[0]:
+        assert torch.isfinite(res[0][n]).all(), n
+        close(res[0][n], res[1][n].double(), f"{encoder} grad {n}: lists + skipped blocks vs all rows", tol=2e-5,
+              floor=1e-3 * float(res[1][n].abs().max()) + 1e-12)
