@@ -116,7 +116,7 @@ class FlatAdam:
             plan.prepare(self.flat)
             tape = leaf[:1]
             for prefix, mod in self._plan_sections:
-                mod._fast = (plan.P[prefix], plan.G[prefix], plan.state, tape)
+                object.__setattr__(mod, "_fast", (plan.P[prefix], plan.G[prefix], plan.state, tape))   # (nn.Module.__setattr__: 6 us)
                 hooked.append(mod)
         # The views stand in for the parameters during the call -- what torch.func.functional_call does, without its
         # per-call walk over the module tree (0.3 ms of host time per step; the RelGCN step is 1.5 ms): every registration
@@ -130,7 +130,7 @@ class FlatAdam:
             for (reg, key, orig), _k in slots:
                 reg[key] = orig
             for mod in hooked:
-                mod._fast = None
+                object.__setattr__(mod, "_fast", None)
 
     def functional_loss(self, *args, t):
         """``functional_forward`` through the module's ``forward_loss`` (GraphConvPredictorForPair: the reference's Classifier,

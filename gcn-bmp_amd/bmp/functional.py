@@ -679,84 +679,6 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
-# All T steps of the planned GGNN forward in one launch (PTStepsFn): built, bit-identical to the per-step launches, and measured
-# SLOWER on every leg (DESIGN.md 3a'': C2 -1.4 %, predict -4 %): off unless BMP_TSTEPS=1.
-_TSTEPS = os.environ.get("BMP_TSTEPS", "0") == "1"
-
-
-def tsteps_supported(d: int, T: int) -> bool:
-    return _TSTEPS and d in (64, 128) and step_supported(d) and 1 <= T <= 8
-
-
-class PTStepsFn(Function):
-    """ALL propagation steps of the planned GGNN encoder as ONE forward launch per chain of tiles (bmp_ggnn_steps_fwd; SURVEY.md
-    section 7 step 9; models/ggnn.py:616-623): the tile's atom states stay in LDS from step to step, every step's m, r|z, c, h'
-    are written for the backward, which stays per step (each step's weight-gradient launch runs beside the chain as soon as its
-    gda exists).  ``steps``: per step (W, G, gkey, first) as PStepFn takes them; ``bufs``: per step (m, rz, c, hout)."""
-
-    @staticmethod
-    def forward(ctx, h, pb, steps, state, bufs):
-        L = _lib.lib()
-        require_rows(h, "steps: h")
-        _check_pb(pb, h)
-        N, d = h.shape
-        T = len(steps)
-        Ws = [s_[0] for s_ in steps]
-        first0 = int(steps[0][3])
-        if any(int(s_[3]) for s_ in steps[1:]):
-            raise ValueError("steps: only step 0 can be the GRU's first call after reset")
-        m = [b_[0] for b_ in bufs]; rz = [b_[1] for b_ in bufs]; c = [b_[2] for b_ in bufs]; hout = [b_[3] for b_ in bufs]
-        keep = m[0] is not None
-        aWT, abE = _ptr_array([W["WTp"] for W in Ws]), _ptr_array([W["bE"] for W in Ws])
-        aAT, ab = _ptr_array([W["ATp"] for W in Ws]), _ptr_array([W["b"] for W in Ws])
-        am, arz, ac, ah = _ptr_array(m), _ptr_array(rz), _ptr_array(c), _ptr_array(hout)
-        flat = tuple(t for b_ in bufs for t in b_ if t is not None)
-        for t0, nt, st in _fwd_parts(state, pb, (h,) + flat):
-            check(L.bmp_ggnn_steps_fwd(ptr(h), t0, nt, d, T, first0, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), aWT, abE, aAT,
-                                       ptr(Ws[0]["UcTp"]), ab, am if keep else None, arz if keep else None, ac if keep else None, ah,
-                                       ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, st), "bmp_ggnn_steps_fwd")
-        ctx.save_for_backward(h, *flat)
-        ctx.pb, ctx.steps, ctx.state, ctx.T, ctx.keep = pb, steps, state, T, keep
-        if keep:
-            type_rows(pb)               # (once per batch, on the chain's stream)
-        for s_ in steps:
-            _register(state, s_[2])
-        return hout[-1]
-
-    @staticmethod
-    def backward(ctx, dhout):
-        L = _lib.lib()
-        if not ctx.keep:
-            raise RuntimeError("steps: the forward ran without keeping m / rz / c (forward-only evaluation)")
-        sv = ctx.saved_tensors
-        h0 = sv[0]
-        pb, steps, T = ctx.pb, ctx.steps, ctx.T
-        bufs = [sv[1 + 4 * t: 5 + 4 * t] for t in range(T)]
-        N, d = h0.shape
-        dh = dhout.contiguous()
-        tri, trc, skip = step_lists(pb, N, d)
-        for t in range(T - 1, -1, -1):
-            W, G, gkey, first = steps[t]
-            m, rz, c, _hout = bufs[t]
-            h_in = h0 if t == 0 else bufs[t - 1][3]
-            dprev = torch.empty(N, d, dtype=torch.float32, device=h0.device)
-            gda = torch.empty(N, 7 * d, dtype=torch.float32, device=h0.device)
-            check(L.bmp_ggnn_step_bwd(ptr(dh), ptr(h_in), ptr(rz), ptr(c), pb.n_mtiles, d, int(first), ptr(pb.csrT_ptr),
-                                      ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
-                                      ptr(dprev), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()), "bmp_ggnn_step_bwd")
-            acc = 0 if _first_write(ctx.state, gkey) else 1
-
-            def wgrad(st, ws_of, h_in=h_in, m=m, rz=rz, gda=gda, G=G, first=first, acc=acc):
-                nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
-                ws = ws_of(nws, h0.device)
-                check(L.bmp_ggnn_step_wgrad(ptr(h_in), ptr(m), ptr(rz), ptr(gda), N, d, int(first), ptr(G["o1"]), ptr(G["o2"]),
-                                            ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(tri), ptr(trc), ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
-
-            _on_side(ctx.state, (h_in, m, rz, gda), wgrad)
-            dh = dprev
-        return dh, None, None, None, None
-
-
 class PReadoutFn(Function):
     """ReadoutFn on prepared weights.  W: WT, b, Wnat; G: dWT, db.
 

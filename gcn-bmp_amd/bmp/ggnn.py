@@ -414,12 +414,8 @@ class GGNN(nn.Module):
             g = f"g{li}_{mode}"
             Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
             per_step.append((W, Gs, g, step == 0))
-        if Fn.tsteps_supported(self.hidden_dim, self.n_layers):
-            # all steps of a tile in one launch per chain, the atom states resident in LDS (models/ggnn.py:616-623)
-            h = Fn.PTStepsFn.apply(h, pb, per_step, state, bufs)
-        else:
-            for step, (W, Gs, g, first) in enumerate(per_step):
-                h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, first, bufs[step])
+        for step, (W, Gs, g, first) in enumerate(per_step):
+            h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, first, bufs[step])
         Fn._join_parts(state)                 # the steps ran as two chains of tiles: whole arrays are read from here on
         return h, h0
 

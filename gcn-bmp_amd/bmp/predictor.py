@@ -76,24 +76,26 @@ class GraphConvPredictorForPair(nn.Module):
     def _forward(self, atoms_1, adjs_1, atoms_2, adjs_2, t):
         # A co-attention of the fine family replaces the encoder's molecule vectors without reading them (:96 with
         # nie_coattention.py:335-370): the readout is computed all the same, but a planned encoder may take it off the chain
-        self.graph_conv._readout_off_chain = bool(getattr(self.attn, "ignores_graph_vectors", False))
+        put = object.__setattr__         # (plain attributes: nn.Module.__setattr__ costs 5 us a time on a 1 ms step)
+        put(self.graph_conv, "_readout_off_chain", bool(getattr(self.attn, "ignores_graph_vectors", False)))
         try:
             g1, g2, at1, at2, mol0 = self._encode(atoms_1, adjs_1, atoms_2, adjs_2)
         finally:
-            self.graph_conv._readout_off_chain = False
+            put(self.graph_conv, "_readout_off_chain", False)
         if self.attn is not None:
             g1, g2 = self.attn(at1, g1, at2, g2, mol0=mol0)                  # train_binary.py:96
         fast = getattr(self.graph_conv, "_fast", None)
         if fast is not None:             # a co-attention off the planned path never flushed the readout the encoder held back
             from .functional import flush_deferred
             flush_deferred(fast[2])
-        self.g1, self.g2 = g1, g2
+        put(self, "g1", g1); put(self, "g2", g2)
         if t is None:
             return self.mlp(g1, g2)      # MLP on [g1 | g2] :98-101 (no concatenation copy); NTN / HolE / ... :102-116
         if callable(getattr(self.mlp, "forward_loss", None)):
-            loss, self.y = self.mlp.forward_loss(g1, g2, t)
+            loss, y = self.mlp.forward_loss(g1, g2, t)
+            put(self, "y", y)
             return loss
-        self.y = self.mlp(g1, g2)
+        put(self, "y", self.mlp(g1, g2))
         return self.loss(self.y, t)
 
     def predict(self, atoms_1, adjs_1=None, atoms_2=None, adjs_2=None):

@@ -20,7 +20,7 @@
 
 // SAVE == false: forward-only evaluation (m, r|z, c are not kept).  The epilogues' arithmetic is written with explicit fused
 // multiply-adds so that both instances round alike: predict's logits are bit for bit the training forward's.
-template <int D, bool FIRST, bool VAR, bool SAVE, bool TS>
+template <int D, bool FIRST, bool VAR, bool SAVE>
 __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     constexpr int LD = D + 4;
     constexpr int NCB = D / 32, NRW = 8 / NCB, RB = 4 / NRW;
@@ -65,11 +65,11 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     const RowOrder ro = FZ_ROW_ORDER();      // the half's rows by (rare bond type, row): the order of the message phase
     const int bi = wr & 1;                   // (RB == 1: this wave's block inside its half)
 
-    // one propagation step on the resident tile (Hs): message, gates, h'.  A generic lambda so that the first call after reset
-    // (no r gate, no U term: FST) and the later calls are two instances of the same text inside ONE kernel (TS: all T steps of
-    // a tile in one launch; models/ggnn.py:616-623 -- a tile's molecules are self-contained across steps).
+    // one propagation step on the resident tile (Hs): message, gates, h'.  (A lambda over the GRU form: the first call after
+    // reset has no r gate and no U term.  A variant running all T steps of a tile in one launch was built in round 3 on this
+    // text, measured slower on every leg -- 256 VGPRs and scratch -- and taken out again in round 4: DESIGN.md 3a''.)
     auto step = [&](auto first_c, const float* WTs, const float* bEs, const float* ATs, const float* bvs, float* om, float* orz,
-                    float* oc, float* oh, bool more) {
+                    float* oc, float* oh) {
         constexpr bool FST = decltype(first_c)::value;
         int tmask = 0;
         // ---- message: m = sum_e AGG_e . W_e + wdeg_e * b_e   (models/ggnn.py:223-242) ----
@@ -177,27 +177,10 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
                 if (!FST) hn = __builtin_fmaf(1.f - zv, Hl[LOFF(rb, reg)], hn);
                 if (save) acc_st<D>(co, rb, reg, cv);
                 acc_st<D>(ho, rb, reg, hn);
-                if (TS) acc_g[2][rb][reg] = hn;          // stays in registers for the write-back into the resident tile
             }
         }
-        if (TS && more) {
-            // the next step reads the WHOLE tile (a neighbour may sit in the other half): every wave of the workgroup is done
-            // reading this step's h before anyone overwrites it, and sees the new one before it gathers from it
-            __syncthreads();
-            FZ_FOR_ACC { Hl[LOFF(rb, reg)] = acc_g[2][rb][reg]; }
-            __syncthreads();
-        }
     };
-    if constexpr (!TS) {
-        step(std::integral_constant<bool, FIRST>{}, a.WT, a.bE, a.AT, a.b, a.m, a.rz, a.c, a.hout, false);
-    } else {
-        // step 0 is the GRU's first call after reset iff FIRST; the steps behind it are later calls
-        step(std::integral_constant<bool, FIRST>{}, a.ts_WT[0], a.ts_bE[0], a.ts_AT[0], a.ts_b[0], a.ts_m[0], a.ts_rz[0], a.ts_c[0],
-             a.ts_hout[0], a.T > 1);
-        for (int t = 1; t < a.T; ++t)
-            step(std::integral_constant<bool, false>{}, a.ts_WT[t], a.ts_bE[t], a.ts_AT[t], a.ts_b[t], a.ts_m[t], a.ts_rz[t], a.ts_c[t],
-                 a.ts_hout[t], t + 1 < a.T);
-    }
+    step(std::integral_constant<bool, FIRST>{}, a.WT, a.bE, a.AT, a.b, a.m, a.rz, a.c, a.hout);
 }
 
 // Backward of one step for one tile: all of the backward-data path (gate derivatives, the three
@@ -722,27 +705,20 @@ extern "C" int bmp_ggnn_step_supported(int d) { return fz_wide(d) || d == 32; }
 // `rows`: rows the launch works on (flop / byte accounting of the roofline leg: with a tile table the live rows, passed by the caller).
 template <int D, bool FIRST, bool VAR>
 static int fz_launch3(bool bwd, const StepArgs& a, int n_tiles, double rows, hipStream_t st) {
-    // kind: 0 forward keeping m / rz / c, 1 forward-only evaluation, 2 backward, 3 / 4: all T steps in one forward launch
-    const bool ts = !bwd && a.T > 0;
-    const bool keep = ts ? a.ts_m[0] != nullptr : a.m != nullptr;
-    const int kind = bwd ? 2 : (ts ? (keep ? 3 : 4) : (keep ? 0 : 1));
+    // kind: 0 forward keeping m / rz / c, 1 forward-only evaluation, 2 backward
+    const bool keep = a.m != nullptr;
+    const int kind = bwd ? 2 : (keep ? 0 : 1);
     const void* fn = bwd ? (const void*)k_ggnn_step_bwd<D, FIRST, VAR>
-                   : kind == 0 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true, false>
-                   : kind == 1 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false, false>
-                   : kind == 3 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true, true>
-                               : (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false, true>;
+                   : kind == 0 ? (const void*)k_ggnn_step_fwd<D, FIRST, VAR, true>
+                               : (const void*)k_ggnn_step_fwd<D, FIRST, VAR, false>;
     if (int rc_attr = bmp_lds_attr(fn, (size_t)((int)fz_lds_bytes(D)))) return rc_attr;
     const double gates = FIRST ? 4.0 : 7.0;                         // d^2 MACs per row: W-part (+U)
-    // (all T steps in one launch: the first step's work + T - 1 later steps')
-    const double macs = ts ? (4.0 + gates) + (a.T - 1) * 11.0 : (4.0 + gates);
+    const double macs = 4.0 + gates;
     BmpProfScope prof(bwd ? BMP_KCLS_STEP_BWD : BMP_KCLS_STEP_FWD, 2.0 * rows * macs * D * D,
-                      4.0 * rows * D * (bwd ? 13.0 : (ts ? 1.0 + 5.0 * a.T : 6.0)), st,
-                      ts ? BMP_KID_GGNN_TSTEPS : (FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER));
+                      4.0 * rows * D * (bwd ? 13.0 : 6.0), st, FIRST ? BMP_KID_GGNN_FIRST : BMP_KID_GGNN_LATER);
     if (bwd) hipLaunchKernelGGL((k_ggnn_step_bwd<D, FIRST, VAR>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else if (kind == 0) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else if (kind == 1) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else if (kind == 3) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
-    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else if (kind == 0) hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, true>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
+    else hipLaunchKernelGGL((k_ggnn_step_fwd<D, FIRST, VAR, false>), dim3(n_tiles), dim3(512), fz_lds_bytes(D), st, a);
     BMP_LAUNCH_CHECK();
     return 0;
 }
@@ -772,33 +748,6 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, 
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
 
-// ALL T propagation steps of every tile in ONE forward launch (models/ggnn.py:616-623: a tile's
-// molecules are self-contained across steps): the tile's atom states stay in LDS from step to step, every step writes the m,
-// r|z, c and h' the per-step backward reads (or only h' of the last step when the m / rz / c arrays are NULL: forward-only
-// evaluation).  WT, bE, AT, b, m, rz, c, hout: HOST arrays of T device pointers (step t's message weights and GRU operands --
-// the same pointers for tied layers; step 0 takes the first-call GRU form when first != 0, the others the later-call form).
-// Bit for bit the per-step launches' results.
-extern "C" int bmp_ggnn_steps_fwd(const float* h, int tile0, int n_tiles, int d, int T, int first, const int* csr_ptr,
-                                  const int* csr_col, const float* csr_val, const float* const* WT, const float* const* bE,
-                                  const float* const* AT, const float* UcT, const float* const* b, float* const* m,
-                                  float* const* rz, float* const* c, float* const* hout, const int* mt_row0, const int* mt_nblk,
-                                  int mt_rows, hipStream_t st) {
-    BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && fz_wide(d) && T >= 1 && T <= FZ_TMAX);
-    BMP_REQUIRE(WT && bE && AT && b && hout && UcT && (mt_row0 != nullptr) == (mt_nblk != nullptr));
-    StepArgs a; memset(&a, 0, sizeof(a));
-    a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
-    a.h = h; a.UcT = UcT; a.T = T;
-    const bool keep = m != nullptr && m[0] != nullptr;
-    for (int t = 0; t < T; ++t) {
-        BMP_REQUIRE(WT[t] && bE[t] && AT[t] && b[t] && hout[t]);
-        a.ts_WT[t] = WT[t]; a.ts_bE[t] = bE[t]; a.ts_AT[t] = AT[t]; a.ts_b[t] = b[t]; a.ts_hout[t] = hout[t];
-        if (keep) {
-            BMP_REQUIRE(m[t] && rz && rz[t] && c && c[t]);
-            a.ts_m[t] = m[t]; a.ts_rz[t] = rz[t]; a.ts_c[t] = c[t];
-        }
-    }
-    return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
-}
 
 // Backward-data of one step: dh (gradient w.r.t. the step input h) and gda [N x 7d] =
 // [G_0..G_3 | da_r | da_z | da_c] for bmp_ggnn_step_wgrad.  Wnat [d x 4d], A [3d x 2d], Uc [d x d].

@@ -8,7 +8,6 @@
 #include "bmp_kernels.h"
 
 #define FZ_R 128
-#define FZ_TMAX 8         // propagation steps of one multi-step forward launch
 
 struct StepArgs {
     // graph
@@ -34,11 +33,7 @@ struct StepArgs {
     const float* Uc;                // [D x D]   (= UcT^T, reference layout)
     float* dh;                      // [N x D]
     float* gda;                     // [N x 7D]: G (4D: gathered dm per bond type) | da_r | da_z | da_c
-    // all T steps of a tile in one forward launch (k_ggnn_step_fwd<.., TS = true>): step t's weights and outputs
-    int T;
     int skip_zero_g;
-    const float* ts_WT[FZ_TMAX]; const float* ts_bE[FZ_TMAX]; const float* ts_AT[FZ_TMAX]; const float* ts_b[FZ_TMAX];
-    float* ts_m[FZ_TMAX]; float* ts_rz[FZ_TMAX]; float* ts_c[FZ_TMAX]; float* ts_hout[FZ_TMAX];
 };
 
 // acc[nb][rb] += A(rows of this wave, K) . B_nb(K, 32 cols)   with A in LDS, B streamed from global.

@@ -134,16 +134,6 @@ int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, 
                       const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
                       const float* b, float* m, float* rz, float* c, float* hout, const int* mt_row0, const int* mt_nblk,
                       int mt_rows, bmp_stream_t stream);
-/* ALL T propagation steps of every tile in ONE forward launch (models/ggnn.py:616-623: a tile's
- * molecules are self-contained across steps): the tile's atom states stay in LDS from step to step; every step writes the m,
- * r|z, c and h' the per-step backward reads (m, rz, c NULL: forward-only evaluation, only the h' arrays are written).  WT, bE,
- * AT, b, m, rz, c, hout are HOST arrays of T <= 8 device pointers (the same pointers for tied layers); step 0 takes the GRU's
- * first-call form when first != 0, the steps behind it the later-call form.  Results bit for bit those of T bmp_ggnn_step_fwd
- * launches. */
-int bmp_ggnn_steps_fwd(const float* h, int tile0, int n_tiles, int d, int T, int first, const int* csr_ptr, const int* csr_col,
-                       const float* csr_val, const float* const* WT, const float* const* bE, const float* const* AT,
-                       const float* UcT, const float* const* b, float* const* m, float* const* rz, float* const* c,
-                       float* const* hout, const int* mt_row0, const int* mt_nblk, int mt_rows, bmp_stream_t stream);
 int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
                       const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
                       const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g,

@@ -489,67 +489,3 @@ def test_low_priority_stream_entry_points():
     assert float(x.sum()) == 3072.0
     check(L.bmp_stream_destroy(hnd), "bmp_stream_destroy")
     assert L.bmp_stream_create_low(None) != 0
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("d", [64, 128])
-@pytest.mark.parametrize("layout", ["instance", "encoder"])
-def test_all_steps_in_one_launch_equal_the_per_step_launches(d, layout):
-    """bmp_ggnn_steps_fwd (the whole propagation loop of a tile in one kernel, atom states resident
-    in LDS; models/ggnn.py:616-623) against T launches of bmp_ggnn_step_fwd: m, r|z, c and h' of every step bit for bit, on
-    whole tiles and on an encoder-layout tile table with short tiles; and the forward-only form (no m / rz / c)."""
-    import ctypes
-    from bmp import _lib, enclayout
-    from bmp._lib import check, ptr, stream
-    from bmp.functional import pack_k4
-    L = _lib.lib()
-    store = synth.make_store(40, seed=3, n_lo=2, n_hi=70, n_mean=20)
-    ms = packed.MolStore(store)
-    rs = np.random.RandomState(1)
-    sides = [rs.randint(0, 40, 60), rs.randint(0, 40, 60)]
-    if layout == "encoder":
-        pbd = enclayout.encode_from_store_device(packed.DeviceMolStore(ms, dev()), sides, n_cu=64).pb_enc
-        assert len(set(pbd.mt_nblk.cpu().tolist())) >= 2
-    else:
-        pbd = to_dev(packed.pack_from_store(ms, sides, device="cpu"))
-    N, T = pbd.n_rows, 4
-    g = torch.Generator().manual_seed(d)
-    r = lambda *s: (0.2 * torch.randn(*s, generator=g)).to(dev())
-    h = r(N, d)
-    WTp, bE, UcTp = pack_k4(r(4 * d, d)), r(4, d), pack_k4(r(d, d))
-    AT1, b1, AT2, b2 = pack_k4(r(2 * d, 3 * d)), r(3 * d), pack_k4(r(2 * d, 3 * d)), r(3 * d)
-    f = lambda *s: torch.full(s, float("nan"), device=dev())
-    mk = lambda: [(f(N, d), f(N, 2 * d), f(N, d), f(N, d)) for _ in range(T)]
-    ref = mk()
-    x = h
-    for t in range(T):
-        m, rz, c, ho = ref[t]
-        check(L.bmp_ggnn_step_fwd(ptr(x), 0, pbd.n_mtiles, d, int(t == 0), ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val),
-                                  ptr(WTp), ptr(bE), ptr(AT1 if t == 0 else AT2), ptr(UcTp), ptr(b1 if t == 0 else b2), ptr(m), ptr(rz),
-                                  ptr(c), ptr(ho), ptr(pbd.mt_row0), ptr(pbd.mt_nblk), N, stream()), "step")
-        x = ho
-    arr = lambda ts: (ctypes.c_void_p * T)(*[None if t_ is None else t_.data_ptr() for t_ in ts])
-    got = mk()
-    check(L.bmp_ggnn_steps_fwd(ptr(h), 0, pbd.n_mtiles, d, T, 1, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), arr([WTp] * T),
-                               arr([bE] * T), arr([AT1] + [AT2] * (T - 1)), ptr(UcTp), arr([b1] + [b2] * (T - 1)),
-                               arr([q[0] for q in got]), arr([q[1] for q in got]), arr([q[2] for q in got]), arr([q[3] for q in got]),
-                               ptr(pbd.mt_row0), ptr(pbd.mt_nblk), N, stream()), "steps")
-    torch.cuda.synchronize()
-    live = torch.zeros(N, dtype=torch.bool, device=dev())
-    if pbd.mt_row0 is None:
-        live[:] = True
-    else:
-        for r0, nb in zip(pbd.mt_row0.cpu().tolist(), pbd.mt_nblk.cpu().tolist()):
-            live[r0:r0 + 32 * nb] = True
-    for t in range(T):
-        for name, a_, b_ in zip(("m", "rz", "c", "hout"), got[t], ref[t]):
-            if name == "rz" and t == 0:
-                a_, b_ = a_[:, d:], b_[:, d:]                  # the first call has no r gate: its r columns are not written
-            assert torch.equal(a_[live], b_[live]), (t, name)
-            assert torch.isfinite(a_[live]).all()
-    only = [f(N, d) for _ in range(T)]
-    check(L.bmp_ggnn_steps_fwd(ptr(h), 0, pbd.n_mtiles, d, T, 1, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), arr([WTp] * T),
-                               arr([bE] * T), arr([AT1] + [AT2] * (T - 1)), ptr(UcTp), arr([b1] + [b2] * (T - 1)), None, None, None,
-                               arr(only), ptr(pbd.mt_row0), ptr(pbd.mt_nblk), N, stream()), "steps (forward only)")
-    torch.cuda.synchronize()
-    assert torch.equal(only[-1][live], ref[-1][3][live])
