@@ -476,15 +476,23 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
     rowgemm_body<WR, RB, CBW, EPI>(a, blockIdx.x, blockIdx.y, lds);
 }
 
-// Up to three independent row GEMMs (generic epilogue) in one launch: row tiles [tx0[p], tx0[p+1]) belong to problem
-// p.  The co-attention's projections are 228 tiles each -- alone, every one of them lasts one workgroup's latency.
-struct RGMulti { RGArgs p[3]; int tx0[4]; int ny[3]; };
+// Up to three independent row GEMMs (generic epilogue) in one launch: x-blocks [bx0[p], bx0[p+1]) belong to problem p.  The
+// co-attention's projections are 228 tiles each -- alone, every one of them lasts one workgroup's latency.
+// A problem whose last column tile holds at most 32 columns (the co-attention's Z = J | P | v: 128 + 16) is cut in two by the
+// launcher: the whole 128-column tiles, and a THIN problem of the remainder that takes 128-row workgroups of ONE 32-column
+// block (each wave 32 rows).  As a second column tile the remainder kept one wave of four busy in a workgroup that staged
+// its rows and lasted as long as a full one: 910 of the 3190 workgroups of that launch.
+#define RGM_MAXP 6
+struct RGMulti { RGArgs p[RGM_MAXP]; int bx0[RGM_MAXP + 1]; int ny[RGM_MAXP]; int thin[RGM_MAXP]; };
 __global__ __launch_bounds__(256) void k_rowgemm_multi(RGMulti m) {
-    __shared__ __attribute__((aligned(16))) float lds[(BMP_R / 2) * BMP_LDS_LD];
-    const int bx = blockIdx.x;                         // 64-row workgroups: two per 128-row tile
-    const int p = bx >= 2 * m.tx0[2] ? 2 : (bx >= 2 * m.tx0[1] ? 1 : 0);
+    __shared__ __attribute__((aligned(16))) float lds[BMP_R * BMP_LDS_LD];
+    const int bx = blockIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < RGM_MAXP; ++q) p += bx >= m.bx0[q] ? 1 : 0;
     if ((int)blockIdx.y >= m.ny[p]) return;
-    rowgemm_body<1, 2, 1, BMP_EPI_GENERIC>(m.p[p], bx - 2 * m.tx0[p], blockIdx.y, lds);
+    if (m.thin[p]) rowgemm_body<4, 1, 1, BMP_EPI_GENERIC>(m.p[p], bx - m.bx0[p], 0, lds);              // 128 rows x 32 columns
+    else rowgemm_body<1, 2, 1, BMP_EPI_GENERIC>(m.p[p], bx - m.bx0[p], blockIdx.y, lds);      // 64-row workgroups: two per tile
 }
 
 template <int EPI>
@@ -545,8 +553,10 @@ int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st) 
 
 int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStream_t st) {
     BMP_REQUIRE(n >= 1 && n <= 3);
+    static const bool no_thin = getenv("BMP_ROWGEMM_NO_THIN") != nullptr;       // A/B: the remainder as a second column tile
     RGMulti m; memset(&m, 0, sizeof(m));
-    int tiles = 0, nymax = 0;
+    int np = 0, nymax = 1;
+    int nt_of[RGM_MAXP];
     double flops = 0, bytes = 0;
     for (int p = 0; p < n; ++p) {
         BMP_REQUIRE(n_tiles[p] > 0 && a[p].Nout > 0 && a[p].nsrc >= 1 && a[p].nsrc <= 3);
@@ -556,16 +566,33 @@ int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStre
             if (a[p].s[s].X2) BMP_REQUIRE((a[p].s[s].ldx2 & 3) == 0 && ((uintptr_t)a[p].s[s].X2 & 15) == 0);
             ksum += a[p].s[s].K;
         }
-        m.p[p] = a[p];
-        m.tx0[p] = tiles; tiles += n_tiles[p];
-        m.ny[p] = (a[p].Nout + 127) / 128;
-        if (m.ny[p] > nymax) nymax = m.ny[p];
         const double rows = (double)n_tiles[p] * BMP_R;
         flops += 2.0 * rows * ksum * a[p].Nout; bytes += 4.0 * rows * (ksum + a[p].Nout);
+        const int rem = a[p].Nout & 127;
+        const bool plain = a[p].split <= 0 && !a[p].add && !a[p].wdeg && !a[p].o1 && !a[p].ridx;
+        m.p[np] = a[p]; nt_of[np] = n_tiles[p];
+        if (!no_thin && plain && a[p].Nout > 128 && rem >= 1 && rem <= 32) m.p[np].Nout = a[p].Nout - rem;
+        m.ny[np] = (m.p[np].Nout + 127) / 128;
+        if (m.ny[np] > nymax) nymax = m.ny[np];
+        ++np;
     }
-    for (int p = n; p <= 3; ++p) m.tx0[p] = tiles;
+    for (int p = 0; p < n; ++p) {          // the thin remainders behind the whole tiles: the long workgroups start first
+        if (m.p[p].Nout == a[p].Nout) continue;
+        const int c0 = m.p[p].Nout;
+        RGArgs t = a[p];
+        t.Nout = a[p].Nout - c0; t.Y = a[p].Y + c0;
+        if (t.bias) t.bias = a[p].bias + c0;
+        for (int s = 0; s < t.nsrc; ++s) t.s[s].Wt = a[p].s[s].Wt + c0;
+        m.p[np] = t; m.thin[np] = 1; m.ny[np] = 1; nt_of[np] = n_tiles[p];
+        ++np;
+    }
+    int blocks = 0;
+    for (int q = 0; q < np; ++q) { m.bx0[q] = blocks; blocks += m.thin[q] ? nt_of[q] : 2 * nt_of[q]; }
+    for (int q = np; q <= RGM_MAXP; ++q) m.bx0[q] = blocks;
+    for (int q = np; q < RGM_MAXP; ++q) m.bx0[q] = 0x7fffffff;      // (the kernel's search never lands behind the last problem)
+    m.bx0[RGM_MAXP] = blocks;
     BmpProfScope prof(BMP_KCLS_ROWGEMM, flops, bytes, st, BMP_KID_ROWGEMM_MULTI);
-    hipLaunchKernelGGL(k_rowgemm_multi, dim3(2 * tiles, nymax), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(k_rowgemm_multi, dim3(blocks, nymax), dim3(256), 0, st, m);
     BMP_LAUNCH_CHECK();
     return 0;
 }
