@@ -435,6 +435,33 @@ def main():
                         streams="side stream (weight gradients) and two forward chains on in the timed region"
                         if side_saved is not None else "one stream")
 
+    def graphed_batch32(e, epoch, n_steps=300):
+        """32-pair steps of Env ``e``, end to end, as replays of one HIP graph on a fixed-shape batch."""
+        from bmp.dp import GraphedTrainStep
+        sb = packed.StaticPairBatch(e.dstore, 32, label_cols=e.label.shape[1])
+        stepper = GraphedTrainStep(e.model, e.opt)
+        perm = np.random.RandomState(1000 + epoch).permutation(len(e.idx1))
+        p1, p2, pl = e.idx1[perm], e.idx2[perm], e.label[perm]
+        host = [0.0]
+
+        def body(i):
+            t0 = time.perf_counter()
+            lo = (i % (len(p1) // 32)) * 32
+            sb.load([p1[lo:lo + 32], p2[lo:lo + 32]], pl[lo:lo + 32])
+            stepper(sb)
+            host[0] += time.perf_counter() - t0
+        for i in range(10):                 # (the first call warms up and records)
+            body(i)
+        host[0] = 0.0
+        sb.wait_seconds = 0.0
+        dt_g, _ = timed(n_steps, lambda i: body(i + 10))
+        host[0] -= sb.wait_seconds          # (load() blocks when the host is four steps ahead of the GPU: waiting, not work)
+        loss_g = float(stepper.graphs[next(iter(stepper.graphs))][1].detach())
+        v = 32 * n_steps / dt_g
+        return dict(value=round(v, 1), unit="pairs/s", steps=n_steps, ms_per_step=round(1e3 * dt_g / n_steps, 3),
+                    host_ms_per_step=round(1e3 * host[0] / n_steps, 3), loss=round(loss_g, 5),
+                    f32_frac=round(v * e.alg_f / (PEAK_F32_TFLOPS * 1e12), 5), mode="hip graph on a fixed-shape batch")
+
     env = Env(args.config)
     atoms_per_pair_main, real_row_fraction_main = env.atoms_per_pair, env.n_atoms / env.n_rows
     env_main_batch0 = env.batches[0][0]
@@ -484,6 +511,7 @@ def main():
                         "the host runs ahead of the GPU.  One epoch: fresh permutation, per step host plan + pinned H2D (plan table, labels, pair metadata) + "
                         "bmp_collate_emit from the HBM-resident store, then the training step; nothing pre-packed")
         if args.config == "c2" and world == 1:
+            graph32 = graphed_batch32(env, epoch=2)
             st = dict(epoch=1, B=32, layout=None if LAYOUT != "auto" else "encoder")
             body = epoch_body(st)
             for i in range(10):
@@ -497,12 +525,17 @@ def main():
             if args.host_profile:
                 prof.disable()
                 pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
-            b32 = dict(value=round(32 * n32 / dt_32, 1), unit="pairs/s", steps=n32, ms_per_step=round(1e3 * dt_32 / n32, 3),
-                       host_ms_per_step=round(1e3 * st["host_s"] / n32, 3), layout=st["layout"] or LAYOUT,
-                       what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end; the "
-                            "encoder layout gives every molecule a tile of its own height, spread over the CUs; host_ms_per_step = time the "
-                            "host spends inside a step's calls (collate + ~55 launches through the framework's autograd): when it equals "
-                            "ms_per_step the leg measures the host, not the GPU path")
+            eager32 = dict(value=round(32 * n32 / dt_32, 1), unit="pairs/s", steps=n32, ms_per_step=round(1e3 * dt_32 / n32, 3),
+                           host_ms_per_step=round(1e3 * st["host_s"] / n32, 3), layout=st["layout"] or LAYOUT,
+                           what="launch by launch through the framework's autograd (collate + ~55 launches per step): "
+                                "host_ms_per_step = ms_per_step, the figure follows the box's host")
+            b32 = dict(graph32, eager=eager32,
+                       what="the same model at the reference's default batch of 32 pairs (train_ddi_modify.py:196), end to end: fresh "
+                            "permutation, per step the host plans the batch (numpy on 64 integers + pair metadata), one pinned H2D "
+                            "copy, then ONE HIP graph -- bmp_collate_emit, forward, loss, backward, weight gradients, Adam, recorded "
+                            "once on a fixed-shape batch (bmp.packed.StaticPairBatch: one molecule per 128-row tile, every pair in "
+                            "the pair kernels' 128-row class) -- is replayed (bmp.dp.GraphedTrainStep); host_ms_per_step = time the "
+                            "host spends in the step's calls.  `eager`: the same steps launch by launch")
         if world == 1:
             # ---- forward-only leg: the evaluation callers' predict (eval_coattention.py:103-124; the evaluator extensions run
             #      it over the train and validation sets every epoch, training/extensions/batch_evaluator.py:49-100) ----
@@ -599,6 +632,7 @@ def main():
                                              host_ms_per_step=round(1e3 * t_host[0] / n_b, 3), steps=n_b,
                                              f32_frac=round(32 * n_b / dt_b * e.alg_f / (PEAK_F32_TFLOPS * 1e12), 5))
                 del b32s
+            ent["batch32_graph"] = graphed_batch32(e, epoch=3, n_steps=200)
             ref_head[name] = ent
             del e
 

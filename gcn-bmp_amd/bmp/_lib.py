@@ -38,8 +38,8 @@ SIGNATURES = {
     "bmp_gru_state_bwd_ws_floats": (_Z, [_I, _I]),
     "bmp_gru_state_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11 + [_Z, _P]),
     "bmp_ggnn_step_supported": (_I, [_I]),
-    "bmp_ggnn_step_fwd": (_I, [_P, _I, _I, _I, _I] + [_P] * 14 + [_I, _P]),
-    "bmp_ggnn_step_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I] + [_P] * 10 + [_I, _I, _P]),
+    "bmp_ggnn_step_fwd": (_I, [_P, _I, _I, _I, _I] + [_P] * 14 + [_I, _I, _P]),
+    "bmp_ggnn_step_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I] + [_P] * 10 + [_I, _I, _I, _P]),
     "bmp_step_wgrad_lists_used": (_I, [_I, _I]),
     "bmp_ggnn_step_wgrad_ws_floats": (_Z, [_I, _I]),
     "bmp_ggnn_step_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),

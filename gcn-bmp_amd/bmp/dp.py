@@ -244,8 +244,9 @@ def shard(n_items: int, rank: int, world: int):
 
 
 class GraphedTrainStep:
-    """One whole training step (forward, loss, backward, gradient all-reduce, Adam) recorded once per distinct batch as
-    a HIP graph and replayed: ~70 launches become one submission.  Measured: at the reference's default batch of 32
+    """One whole training step (forward, loss, backward, gradient all-reduce, Adam) recorded once per distinct batch -- or
+    once for ALL batches of a size, when they are loaded into one ``bmp.packed.StaticPairBatch`` (round 4) -- as a HIP graph
+    and replayed: ~55 launches become one submission and the host's per-launch work leaves the step.  Measured: at the reference's default batch of 32
     pairs (train_ddi_modify.py:196) 1.64 -> 1.57 ms per step -- that step is a chain of ~70 dependent kernels of one
     or two workgroup rounds each, bound by their latencies rather than by the host; at 1024 pairs per GPU the step is
     GPU-bound and gains nothing.  Kept as the host-jitter-free way to run a fixed set of batches.
@@ -261,23 +262,50 @@ class GraphedTrainStep:
             raise ValueError("graphs need a GPU")
         self.model, self.opt, self.warmup = model, opt, warmup
         self.graphs = {}
-        opt._alpha_dev = torch.zeros(1, dtype=torch.float32, device=opt.flat.device)
+        self._alpha = torch.zeros(1, dtype=torch.float32, device=opt.flat.device)
 
     def _set_alpha(self) -> None:
         o = self.opt
-        o._alpha_dev.fill_(o.alpha * math.sqrt(1.0 - o.beta2 ** (o.t + 1)) / (1.0 - o.beta1 ** (o.t + 1)))
+        self._alpha.fill_(o.alpha * math.sqrt(1.0 - o.beta2 ** (o.t + 1)) / (1.0 - o.beta1 ** (o.t + 1)))
 
-    def _body(self, pb, t):
+    def _body(self, pb, t, static=None):
+        plan = self.opt._layout_plan()
+        if plan is None:
+            return self._body_streams(pb, t, static)
+        was = getattr(plan, "in_line", False)
+        plan.in_line = True                 # one in-order chain: what a replay runs back to back (bmp/plan.py: prepare)
+        try:
+            return self._body_streams(pb, t, static)
+        finally:
+            plan.in_line = was
+
+    def _body_streams(self, pb, t, static=None):
         o = self.opt
-        y = o.functional_forward(pb)
-        loss = self.model.loss(y, t)
+        if static is not None:
+            # a batch at fixed addresses (bmp.packed.StaticPairBatch): its arrays are written by the first launch of the step,
+            # and what an earlier step derived from their contents is derived again
+            static.reset_derived()
+            static.emit()
+        if callable(getattr(self.model, "forward_loss", None)):      # the reference's Classifier: link predictor + loss together
+            loss = o.functional_loss(pb, t=t)
+        else:
+            loss = self.model.loss(o.functional_forward(pb), t)
         loss.backward()
         o.collect_grads()
         o.all_reduce_grads()
-        o.step()
+        o._alpha_dev = self._alpha          # Adam reads alpha_t from the device in the recorded step (and only there: eager
+        try:                                # steps between replays take it from the host as ever)
+            o.step()
+        finally:
+            o._alpha_dev = None
         return loss
 
-    def __call__(self, pb, t) -> torch.Tensor:
+    def __call__(self, pb, t=None) -> torch.Tensor:
+        """One step on the batch ``(pb, t)`` -- or on a ``StaticPairBatch`` (``t`` is then its own label array): ONE graph
+        serves every batch loaded into it."""
+        static = pb if callable(getattr(pb, "emit", None)) else None
+        if static is not None:
+            pb, t = static.pb, static.t
         key = (id(pb), id(t))
         o = self.opt
         if key not in self.graphs:
@@ -288,13 +316,13 @@ class GraphedTrainStep:
             with torch.cuda.stream(s):
                 for _ in range(self.warmup):
                     self._set_alpha()
-                    self._body(pb, t)
+                    self._body(pb, t, static)
             torch.cuda.current_stream().wait_stream(s)
             o.flat.copy_(saved[0]); o.m.copy_(saved[1]); o.v.copy_(saved[2]); o.t = saved[3]
             g = torch.cuda.CUDAGraph()
             t_before = o.t
             with torch.cuda.graph(g):
-                loss = self._body(pb, t)
+                loss = self._body(pb, t, static)
             o.t = t_before                      # recording does not execute: the step count advances on replay
             self.graphs[key] = (g, loss, pb, t)
         g, loss, _pb, _t = self.graphs[key]

@@ -223,6 +223,12 @@ def step_lists(pb, N: int, d: int):
     return tri, trc, 1
 
 
+def _rel_mt(pb):
+    """Tile table for the RelGCN layer kernels: they do not clear dead blocks, so a fixed-stride table (pb.tile_stride, the
+    fixed-shape batch) is not handed to them -- its tiles run whole."""
+    return (None, None) if pb.tile_stride else (pb.mt_row0, pb.mt_nblk)
+
+
 def step_supported(d: int) -> bool:
     return bool(_lib.lib().bmp_ggnn_step_supported(int(d)))
 
@@ -268,7 +274,7 @@ class GGNNStepFn(Function):
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
         check(L.bmp_ggnn_step_fwd(ptr(h), 0, pb.n_mtiles, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                   ptr(WTp), ptr(bE), ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout),
-                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()), "bmp_ggnn_step_fwd")
+                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, pb.tile_stride, stream()), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, WT, AT, UcT, m, rz, c)
         ctx.pb, ctx.first, ctx.cache = pb, int(first), cache
         if cache is not None:       # how many steps of this call share both weight sets (see backward)
@@ -292,7 +298,7 @@ class GGNNStepFn(Function):
         tri, trc, skip = step_lists(pb, N, d)
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(Wnat), ptr(A), ptr(Uc), ptr(dh), ptr(gda),
-                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()), "bmp_ggnn_step_bwd")
+                                  ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, pb.tile_stride, skip, stream()), "bmp_ggnn_step_bwd")
         # Steps that share BOTH weight sets (tied layers) accumulate their weight gradients in one set of
         # buffers inside the kernels; only the last of them to run hands the sums to autograd.
         grp = ("g", WT.data_ptr(), AT.data_ptr())
@@ -640,7 +646,7 @@ class PStepFn(Function):
         for t0, nt, st in _fwd_parts(state, pb, (h, m, rz, c, hout)):
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, int(first), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
                                       ptr(W["WTp"]), ptr(W["bE"]), ptr(W["ATp"]), ptr(W["UcTp"]), ptr(W["b"]), ptr(m), ptr(rz),
-                                      ptr(c), ptr(hout), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, st), "bmp_ggnn_step_fwd")
+                                      ptr(c), ptr(hout), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, pb.tile_stride, st), "bmp_ggnn_step_fwd")
         ctx.save_for_backward(h, m, rz, c)
         ctx.pb, ctx.W, ctx.G, ctx.state, ctx.gkey, ctx.first = pb, W, G, state, gkey, int(first)
         if m is not None:
@@ -660,7 +666,7 @@ class PStepFn(Function):
         tri, trc, skip = step_lists(pb, N, d)
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
-                                  ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()), "bmp_ggnn_step_bwd")
+                                  ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, pb.tile_stride, skip, stream()), "bmp_ggnn_step_bwd")
         acc = 0 if _first_write(ctx.state, ctx.gkey) else 1
 
         def wgrad(st, ws_of):
@@ -869,7 +875,7 @@ def _rel_fwd(x, pb, WTp, bE, WsTp, bs, act, state=None, bufs=None):
         type_rows(pb)                   # (once per batch, on the chain's stream: the backward's weight-gradient launches walk them)
     for t0, nt, st in _fwd_parts(state, pb, (x, out, wdeg)):
         check(L.bmp_relgcn_layer_fwd(ptr(x), t0, nt, d, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE),
-                                     ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, st),
+                                     ptr(WsTp), ptr(bs), act, ptr(out), ptr(wdeg), ptr(_rel_mt(pb)[0]), ptr(_rel_mt(pb)[1]), pb.n_rows, st),
               "bmp_relgcn_layer_fwd")
     return out, wdeg
 
@@ -881,7 +887,7 @@ def _rel_bwd(dout, out, x, wdeg, pb, Wnat_p, Ws_p, act, o1, dbE, cs, accumulate,
     gda = torch.empty(N, 5 * d, dtype=torch.float32, device=x.device)
     tri, trc, skip = step_lists(pb, N, d)
     check(L.bmp_relgcn_layer_bwd(ptr(dout), ptr(out), act, pb.n_mtiles, d, ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val),
-                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, skip, stream()),
+                                 ptr(Wnat_p), ptr(Ws_p), ptr(dx), ptr(gda), ptr(_rel_mt(pb)[0]), ptr(_rel_mt(pb)[1]), pb.n_rows, skip, stream()),
               "bmp_relgcn_layer_bwd")
 
     def wgrad(st, ws_of):

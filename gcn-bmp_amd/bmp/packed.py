@@ -148,6 +148,9 @@ class PackedMolBatch:
     mt_row0: Optional[torch.Tensor] = None
     mt_nblk: Optional[torch.Tensor] = None
     n_mtiles: int = -1
+    # 0: the tile table covers dense rows (tile t + 1 follows tile t).  R: tile t starts at row R t whatever its height (the
+    # fixed-shape batch below); the fused step kernels then clear the rows of a tile's dead blocks in what they write.
+    tile_stride: int = 0
     _cache: dict = field(default_factory=dict, repr=False)
 
     def __post_init__(self):
@@ -655,3 +658,147 @@ def pack_from_store_device(dstore: DeviceMolStore, sides: Sequence[np.ndarray], 
     if lab is None:
         return pb
     return pb, up[n_tab + n_meta:].view(np.asarray(labels).shape if np.asarray(labels).ndim > 1 else (-1,))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A batch of a FIXED shape at FIXED device addresses (round 4): what a HIP graph of the training step needs.
+# ---------------------------------------------------------------------------------------------------------
+def plan_one_per_tile(st_nrows: np.ndarray, st_nedges: np.ndarray, sides: Sequence[np.ndarray], R: int, out: np.ndarray,
+                      mt_out: np.ndarray):
+    """The plan table of ``bmp_collate_plan`` (row0 | nrows | mid | ebase | padw | ndead, stride I; ``out``, int32, >= 6 I
+    entries) for the placement "every molecule instance owns one R-row tile", and the tile table (``mt_out``, int32, 2 I
+    entries: mt_row0 [I] | mt_nblk [I], the tile's live 32-row blocks -- they hold the real atoms and the pad row).  Host
+    arithmetic on a few dozen integers; returns (I, n_edges, n_real_atoms)."""
+    mids = np.concatenate([np.asarray(s) for s in sides]).astype(np.int64)
+    I = len(mids)
+    if mids.min() < 0 or mids.max() >= len(st_nrows):
+        raise ValueError("molecule index outside the store")
+    nrows = st_nrows[mids].astype(np.int64)
+    if int(nrows.max()) > R:
+        raise ValueError(f"a molecule of more than {R - 1} atoms does not fit the one-tile-per-molecule placement")
+    ne = st_nedges[mids].astype(np.int64)
+    tab = out[:6 * I].reshape(6, I)
+    tab[0] = np.arange(I) * R
+    tab[1] = nrows
+    tab[2] = mids
+    tab[3] = np.cumsum(ne) - ne
+    lo = 0
+    for s in sides:                     # concat_mols pads every side to its largest molecule (train_ddi_modify.py:296)
+        hi = lo + len(s)
+        tab[4, lo:hi] = int(nrows[lo:hi].max()) - nrows[lo:hi]
+        lo = hi
+    tab[5] = R - nrows
+    mt_out[:I] = tab[0]
+    mt_out[I:2 * I] = (nrows + 31) // 32
+    return I, int(ne.sum()), int(nrows.sum()) - I
+
+
+class StaticPairBatch:
+    """A two-sided batch of ``B`` drug pairs whose arrays live at fixed device addresses and have a fixed shape, so that a
+    training step on it can be recorded ONCE as a HIP graph (bmp.dp.GraphedTrainStep) and replayed for every batch of the
+    epoch: the reference's default of 32 pairs (train_ddi_modify.py:196) is a chain of ~55 launches of one workgroup
+    round each, and the framework's per-launch host work (1.2-1.6 ms per step, by the box) was what the 32-pair leg of
+    bench.py measured.
+
+    Placement: every molecule instance owns one R-row tile; the tile table names its live 32-row blocks, which is all the
+    fused step kernels work on (a step lasts as long as the batch's tallest molecule, as in the encoder layout of
+    bmp/enclayout.py) -- hence N = 2 B R rows, 2 B tiles on 2 B CUs and per-pair row ranges that depend on nothing but B.
+    ``tile_stride = R`` tells those kernels to clear the rows of a tile's other blocks in what they write: the GEMMs that
+    walk all rows (weight gradients, projections) would otherwise read what an earlier batch left there.  The pair kernels take every pair in
+    their 128-row class (a class is an upper bound on the rows of its pairs).  Only the CONTENTS change from batch to batch:
+    ``load`` plans on the host (numpy on 2 B integers + bmp_collate_pair_meta) into a pinned buffer and copies it over;
+    ``emit`` (one launch of bmp_collate_emit, part of the recorded step) writes the packed arrays from the store in HBM."""
+
+    N_STAGE = 4
+
+    def __init__(self, dstore: DeviceMolStore, B: int, label_cols: int = 1, R: int = DEFAULT_R):
+        if dstore.device.type != "cuda":
+            raise ValueError("StaticPairBatch needs the store on a GPU")
+        if int(dstore.st_nrows.max()) > R:
+            raise ValueError(f"the store holds a molecule of more than {R - 1} atoms: no fixed-shape batch for it")
+        self.dstore, self.B, self.R, self.label_cols = dstore, int(B), R, int(label_cols)
+        dev = dstore.device
+        I = 2 * self.B
+        N = I * R
+        e_cap = I * int(dstore.st_nedges.max())
+        self.n_tab, self.n_meta, self.n_mt, self.n_lab = 6 * I, 8 * self.B, 2 * I, self.B * self.label_cols
+        self.n_up = self.n_tab + self.n_meta + self.n_mt + self.n_lab
+        self.up = torch.zeros(self.n_up, dtype=torch.int32, device=dev)
+        ibuf = torch.zeros(4 * N + 2 + 2 * e_cap, dtype=torch.int32, device=dev)
+        fbuf = torch.zeros(N + 2 * e_cap, dtype=torch.float32, device=dev)
+        o = 2 * N + 1 + e_cap
+        up, nt = self.up, self.n_tab
+        m = up[nt:nt + self.n_meta]
+        mt = up[nt + self.n_meta:nt + self.n_meta + self.n_mt]
+        Bp = self.B
+        self.pb = PackedMolBatch(
+            R=R, n_tiles=I, n_mols=I, atom_id=ibuf[:N], row_w=fbuf[:N], csr_ptr=ibuf[N:2 * N + 1], csr_col=ibuf[2 * N + 1:o],
+            csr_val=fbuf[N:N + e_cap], csrT_ptr=ibuf[o:o + N + 1], csrT_col=ibuf[o + N + 1:o + N + 1 + e_cap],
+            csrT_val=fbuf[N + e_cap:], mol_row0=up[:I], mol_nrows=up[I:2 * I], side_tiles=(0, Bp, I), side_mols=(0, Bp, I),
+            n_real_atoms=0, n_edges=e_cap, max_rows_per_mol=R, mol_nrows_host=None, row_mol=ibuf[o + N + 1 + e_cap:o + 2 * N + 1 + e_cap],
+            atom_id_range=dstore.atom_id_range, mt_row0=mt[:I], mt_nblk=mt[I:], n_mtiles=I, tile_stride=R)
+        # every pair in the 128-row class, whatever its size; C blocks at their largest
+        counts = [0, 0, 0, Bp, 0]
+        self.pair_meta = dict(
+            B=Bp, T1=Bp, T2=Bp, coff=m[:2 * Bp].view(torch.int64), r1=m[2 * Bp:3 * Bp], n1=m[3 * Bp:4 * Bp], r2=m[4 * Bp:5 * Bp],
+            n2=m[5 * Bp:6 * Bp], order=m[6 * Bp:7 * Bp], order_f=m[7 * Bp:8 * Bp], counts=counts, counts_f=list(counts),
+            ctotal=Bp * (R * R + 4 * R), np_big=0)
+        lab = up[nt + self.n_meta + self.n_mt:]
+        self.t = lab.view(Bp, self.label_cols) if self.label_cols > 1 else lab.view(Bp, 1)
+        self._stage = [torch.empty(self.n_up, dtype=torch.int32).pin_memory() for _ in range(self.N_STAGE)]
+        self._events = [None] * self.N_STAGE
+        self._k = 0
+        self.n_real_atoms = self.n_edges = 0
+        self.wait_seconds = 0.0            # time ``load`` spent waiting for the GPU to catch up (not host work)
+        self.reset_derived()
+
+    def reset_derived(self) -> None:
+        """Forget what earlier steps derived from the batch's contents (row lists per bond type, rescaled adjacency): the
+        arrays are the same tensors, their contents are not."""
+        self.pb._cache = {"pair_meta": self.pair_meta}
+
+    def load(self, sides: Sequence[np.ndarray], labels: np.ndarray) -> None:
+        """Plan the batch (idx1, idx2) on the host and send the plan, the pair metadata, the tile table and the labels to their
+        fixed place on the device (one pinned copy on the caller's stream).  ``emit`` then writes the packed arrays."""
+        L = _lib_mod().lib()
+        if len(sides) != 2 or len(sides[0]) != self.B or len(sides[1]) != self.B:
+            raise ValueError(f"a StaticPairBatch of {self.B} pairs takes two sides of {self.B} molecules")
+        lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+        if lab.size != self.n_lab:
+            raise ValueError(f"labels: expected {self.B} x {self.label_cols} entries")
+        k = self._k
+        self._k = (k + 1) % self.N_STAGE
+        if self._events[k] is not None:
+            tw = _time.perf_counter()
+            self._events[k].synchronize()          # the copy that last used this pinned buffer: the host is N_STAGE steps ahead
+            self.wait_seconds += _time.perf_counter() - tw
+        st = self._stage[k].numpy()
+        t0 = _time.perf_counter()
+        o_mt = self.n_tab + self.n_meta
+        I, self.n_edges, self.n_real_atoms = plan_one_per_tile(self.dstore.st_nrows, self.dstore.st_nedges, sides, self.R, st,
+                                                               st[o_mt:o_mt + self.n_mt])
+        cnt = np.zeros(6, dtype=np.int32); ct = np.zeros(1, dtype=np.int64)
+        rc = L.bmp_collate_pair_meta(_i32p(st), I, self.B, self.B, self.R, _i32p(st[self.n_tab:]), _i32p(cnt), _i32p(ct))
+        if rc:
+            raise RuntimeError(f"bmp_collate_pair_meta failed ({rc})")
+        st[self.n_tab + self.n_meta + self.n_mt:] = lab
+        self.dstore.plan_seconds += _time.perf_counter() - t0
+        self.dstore.plan_calls += 1
+        self.up.copy_(self._stage[k], non_blocking=True)
+        if self._events[k] is None:
+            self._events[k] = torch.cuda.Event()
+        self._events[k].record()
+
+    def emit(self) -> None:
+        """bmp_collate_emit on the caller's stream, into the fixed arrays (recorded with the step when a graph is captured)."""
+        from ._lib import check, ptr, stream
+        L = _lib_mod().lib()
+        d, pb = self.dstore.dev, self.pb
+        check(L.bmp_collate_emit(ptr(self.up), 2 * self.B, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), ptr(d[5]), ptr(d[6]),
+                                 ptr(pb.atom_id), ptr(pb.row_w), ptr(pb.row_mol), ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val),
+                                 ptr(pb.csrT_ptr), ptr(pb.csrT_col), ptr(pb.csrT_val), None, stream()), "bmp_collate_emit")
+
+
+def _lib_mod():
+    from . import _lib
+    return _lib

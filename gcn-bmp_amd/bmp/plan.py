@@ -260,9 +260,12 @@ class LayoutPlan:
         if self.state.get("split_open"):
             self.state["split"].join()
         self.state = {}                              # (drops split_keep / the side stream's keep list: both streams are joined)
-        if self.side is not None:
+        # in_line (set by bmp.dp.GraphedTrainStep while it records a step): every launch on the caller's stream.  A replayed
+        # HIP graph runs a single in-order chain back to back, while every cross-stream edge of a recording costs tens of
+        # microseconds per replay (32-pair step: 1.25 ms recorded in line, 1.52 ms with the side stream and the second chain)
+        if self.side is not None and not getattr(self, "in_line", False):
             self.state["side"] = self.side
-        if self.split is not None:
+        if self.split is not None and not getattr(self, "in_line", False):
             self.state["split"] = self.split
         self.gk.zero_()          # a buffer no backward kernel writes this step (an unused readout, ...) must read as zero
 

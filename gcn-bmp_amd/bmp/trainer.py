@@ -106,6 +106,9 @@ def evaluate(predictor, batches: Iterable, lossfun: Optional[Callable] = None, i
     predictor.eval()
     with torch.no_grad():
         for inputs, t in batches:
+            if callable(getattr(inputs, "emit", None)):          # a fixed-shape batch (PairBatches(layout="static")): write its arrays
+                inputs.reset_derived(); inputs.emit()
+                inputs = inputs.pb
             if opt is not None:
                 y = opt.functional_predict(*inputs)[0] if isinstance(inputs, (tuple, list)) else opt.functional_predict(inputs)[0]
             else:
@@ -165,14 +168,18 @@ class PairBatches:
 
     ``layout`` "instance": bmp.packed.pack_from_store_device.  "encoder": bmp.enclayout.encode_from_store_device (encoder
     tiles balanced over the CUs); with ``dedup`` every distinct molecule of this rank's share is encoded once and its atom
-    states are copied to the instances -- the same logits and gradients, fewer encoder rows.  With ``world`` > 1 a global
+    states are copied to the instances -- the same logits and gradients, fewer encoder rows.  "static": every full batch is
+    loaded into ONE fixed-shape batch (bmp.packed.StaticPairBatch: the same object is yielded every time, its contents change),
+    on which ``fit`` replays one recorded HIP graph per step -- the way to run small batches such as the reference's default of
+    32 pairs (train_ddi_modify.py:196), where a step is ~55 launches of one workgroup round each; the short remainder of a pass
+    comes as a usual packed batch.  With ``world`` > 1 a global
     batch is ``batch_size * world`` pairs and this rank takes its contiguous share (a remainder smaller than ``world`` is
     left out, so that no rank steps on an empty batch)."""
 
     def __init__(self, dstore, idx1: np.ndarray, idx2: np.ndarray, labels: np.ndarray, batch_size: int, shuffle: bool = False,
                  seed: int = 0, layout: str = "instance", dedup: bool = False, rank: int = 0, world: int = 1):
-        if layout not in ("instance", "encoder"):
-            raise ValueError(f"layout {layout!r}: 'instance' or 'encoder'")
+        if layout not in ("instance", "encoder", "static"):
+            raise ValueError(f"layout {layout!r}: 'instance', 'encoder' or 'static'")
         if dedup and layout != "encoder":
             raise ValueError("dedup needs layout='encoder'")
         if not (len(idx1) == len(idx2) == len(labels)):
@@ -203,7 +210,12 @@ class PairBatches:
         from . import enclayout, packed
         for sel in self.selections():
             sides, lab = [self.i1[sel], self.i2[sel]], self.lab[sel]
-            if self.layout == "encoder":
+            if self.layout == "static" and len(sel) == self.B:
+                if getattr(self, "_static", None) is None:
+                    self._static = packed.StaticPairBatch(self.dstore, self.B, label_cols=int(np.asarray(lab).reshape(len(sel), -1).shape[1]))
+                self._static.load(sides, lab)
+                yield self._static, self._static.t
+            elif self.layout == "encoder":
                 yield enclayout.encode_from_store_device(self.dstore, sides, labels=lab, dedup=self.dedup)
             else:
                 yield packed.pack_from_store_device(self.dstore, sides, labels=lab)
@@ -216,9 +228,18 @@ def fit(model, opt, train_batches: Sequence, valid_batches: Sequence = (), epoch
     backward, one gradient all-reduce, Adam; per epoch the evaluators, the alpha shift and the stop trigger."""
     logs: List[Dict[str, float]] = []
     t0 = time.time()
+    stepper = None
     for epoch in range(1, epochs + 1):
         tot, n = None, 0
         for pb, t in train_batches:
+            if callable(getattr(pb, "emit", None)):                 # a fixed-shape batch: the whole step is one graph replay
+                if stepper is None:
+                    from .dp import GraphedTrainStep
+                    stepper = GraphedTrainStep(model, opt)
+                loss = stepper(pb)
+                tot = loss.detach() * len(t) if tot is None else tot + loss.detach() * len(t)
+                n += len(t)
+                continue
             if callable(getattr(model, "forward_loss", None)):      # the reference's Classifier: link predictor + loss together
                 loss = opt.functional_loss(*(pb if isinstance(pb, (tuple, list)) else (pb,)), t=t)
             else:

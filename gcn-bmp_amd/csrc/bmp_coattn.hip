@@ -107,7 +107,9 @@ __device__ __forceinline__ CoLds co_carve(float* base, int np, int ldc, int H, b
 
 static size_t co_lds_floats(int np, int ldc, int H, bool bwd, int o = 0, int nt = 256, bool big = false) {
     return (size_t)np * ldc * (bwd ? 2 : 1) + (size_t)np * H * (bwd ? 6 : 2) + 11 * (size_t)np + (bwd ? 2 * (size_t)o + np : 0) +
-           (big ? (bwd ? np + np * (size_t)H : 0) : ((bwd && np < 128) ? nt + nt * (size_t)H : 0)) + 8;
+           (big ? (bwd ? np + np * (size_t)H : 0) : ((bwd && np < 128) ? nt + nt * (size_t)H : 0));
+    // (no slack behind the last array: the backward of the 128-row class at o = 128, H = 8 is EXACTLY the CU's 160 KB -- eight
+    //  spare floats used to put it past the limit, and a pair with a molecule of 96..127 atoms failed the launcher's check)
 }
 // the oversized class: rows rounded up to 32, the forward's pooled-output scratch (2 * NT floats) fits in the C image
 static int co_big_np(int np_big) { return (np_big + 31) & ~31; }

@@ -41,6 +41,13 @@ __global__ __launch_bounds__(512) void k_ggnn_step_fwd(StepArgs a) {
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
     FZ_TILE_SETUP();
+    if (VAR && a.tile_stride > nrows) {      // a tile of a fixed-stride table: its blocks without atoms, in every array written
+        const int e = row0 + a.tile_stride;
+        fz_clear_rows<512>(a.hout, D, row0 + nrows, e, tid);
+        fz_clear_rows<512>(a.m, D, row0 + nrows, e, tid);
+        fz_clear_rows<512>(a.rz, 2 * D, row0 + nrows, e, tid);
+        fz_clear_rows<512>(a.c, D, row0 + nrows, e, tid);
+    }
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;         // this lane's row for reg 0 of row block 0
@@ -215,6 +222,11 @@ __global__ __launch_bounds__(512) void k_ggnn_step_bwd(StepArgs a) {
     const int wc = w % NCB, wr = w / NCB;
     const int l31 = lane & 31, hi = lane >> 5;
     FZ_TILE_SETUP();
+    if (VAR && a.tile_stride > nrows) {      // (fixed-stride tile table: the tile's blocks without atoms read as zero to the
+        const int e = row0 + a.tile_stride;  //  weight-gradient GEMMs and to the step below)
+        fz_clear_rows<512>(a.dh, D, row0 + nrows, e, tid);
+        fz_clear_rows<512>(a.gda, 7 * D, row0 + nrows, e, tid);
+    }
     const int col = wc * 32 + l31;
     const int wrow0 = wr * RB * 32;
     const int lrow = wrow0 + 4 * hi;
@@ -737,13 +749,15 @@ static int fz_launch(bool bwd, const StepArgs& a, int n_tiles, hipStream_t st) {
 extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr,
                                  const int* csr_col, const float* csr_val, const float* WT, const float* bE, const float* AT,
                                  const float* UcT, const float* b, float* m, float* rz, float* c, float* hout,
-                                 const int* mt_row0, const int* mt_nblk, int mt_rows, hipStream_t st) {
+                                 const int* mt_row0, const int* mt_nblk, int mt_rows, int tile_stride, hipStream_t st) {
     BMP_REQUIRE(tile0 >= 0 && n_tiles > 0 && bmp_ggnn_step_supported(d));
+    BMP_REQUIRE(tile_stride == 0 || (tile_stride == FZ_R && mt_row0 != nullptr));
     BMP_REQUIRE((m != nullptr) == (rz != nullptr) && (m != nullptr) == (c != nullptr) && hout != nullptr);
     StepArgs a; memset(&a, 0, sizeof(a));
     BMP_REQUIRE((mt_row0 != nullptr) == (mt_nblk != nullptr));
     a.ptr = csr_ptr; a.col = csr_col; a.val = csr_val; a.first = first; a.tile0 = tile0; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.h = h; a.WT = WT; a.bE = bE; a.AT = AT; a.UcT = UcT; a.b = b; a.m = m; a.rz = rz; a.c = c; a.hout = hout;
+    a.tile_stride = tile_stride;
     if (!fz_wide(d)) return bmp_launch_step_small(false, a, n_tiles, d, st);
     return d == 128 ? fz_launch<128>(false, a, n_tiles, st) : fz_launch<64>(false, a, n_tiles, st);
 }
@@ -757,11 +771,13 @@ extern "C" int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, 
 extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d,
                                  int first, const int* csrT_ptr, const int* csrT_col, const float* csrT_val,
                                  const float* Wnat, const float* A, const float* Uc, float* dh, float* gda,
-                                 const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g, hipStream_t st) {
+                                 const int* mt_row0, const int* mt_nblk, int mt_rows, int tile_stride, int skip_zero_g, hipStream_t st) {
     BMP_REQUIRE(n_tiles > 0 && bmp_ggnn_step_supported(d) && (mt_row0 != nullptr) == (mt_nblk != nullptr));
     StepArgs a; memset(&a, 0, sizeof(a));
     a.ptr = csrT_ptr; a.col = csrT_col; a.val = csrT_val; a.first = first; a.mt_row0 = mt_row0; a.mt_nblk = mt_nblk; a.mt_rows = mt_rows;
     a.dhout = dhout; a.h = h; a.rz = const_cast<float*>(rz); a.c = const_cast<float*>(c); a.Wnat = Wnat; a.A = A; a.Uc = Uc; a.dh = dh; a.gda = gda;
+    BMP_REQUIRE(tile_stride == 0 || (tile_stride == FZ_R && mt_row0 != nullptr));
+    a.tile_stride = tile_stride;
     a.skip_zero_g = skip_zero_g && fz_wide(d);
     if (!fz_wide(d)) return bmp_launch_step_small(true, a, n_tiles, d, st);
     return d == 128 ? fz_launch<128>(true, a, n_tiles, st) : fz_launch<64>(true, a, n_tiles, st);

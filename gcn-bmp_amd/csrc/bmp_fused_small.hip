@@ -103,6 +103,13 @@ __global__ __launch_bounds__(FS_NT) void k_ggnn_step_fwd_s(StepArgs a) {
     const int row0 = VAR ? a.mt_row0[tile] : tile * FS_R;
     const int nblk = VAR ? a.mt_nblk[tile] : 4;
     const int nrows = nblk * 32;
+    if (VAR && a.tile_stride > nrows) {      // fixed-stride tile table (bmp_tile.h, StepArgs::tile_stride): the blocks without atoms
+        const int e = row0 + a.tile_stride;
+        fz_clear_rows<FS_NT>(a.hout, D, row0 + nrows, e, tid);
+        fz_clear_rows<FS_NT>(a.m, D, row0 + nrows, e, tid);
+        fz_clear_rows<FS_NT>(a.rz, 2 * D, row0 + nrows, e, tid);
+        fz_clear_rows<FS_NT>(a.c, D, row0 + nrows, e, tid);
+    }
     const int col = l31;
     const int wrow0 = w * 32;
     const int lrow = wrow0 + 4 * hi;         // this lane's row for accumulator register 0
@@ -239,6 +246,11 @@ __global__ __launch_bounds__(FS_NT) void k_ggnn_step_bwd_s(StepArgs a) {
     const int row0 = VAR ? a.mt_row0[tile] : tile * FS_R;
     const int nblk = VAR ? a.mt_nblk[tile] : 4;
     const int nrows = nblk * 32;
+    if (VAR && a.tile_stride > nrows) {
+        const int e = row0 + a.tile_stride;
+        fz_clear_rows<FS_NT>(a.dh, D, row0 + nrows, e, tid);
+        fz_clear_rows<FS_NT>(a.gda, 7 * D, row0 + nrows, e, tid);
+    }
     const int col = l31;
     const int wrow0 = w * 32;
     const int lrow = wrow0 + 4 * hi;

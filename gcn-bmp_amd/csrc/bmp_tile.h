@@ -34,7 +34,21 @@ struct StepArgs {
     float* dh;                      // [N x D]
     float* gda;                     // [N x 7D]: G (4D: gathered dm per bond type) | da_r | da_z | da_c
     int skip_zero_g;
+    // tile table at a FIXED stride (bmp.packed.StaticPairBatch: tile t starts at row t * tile_stride, its mt_nblk[t] live blocks
+    // hold its molecule): the rows of the tile's other blocks are cleared in every array the launch writes, so that what an
+    // earlier batch left there never enters a GEMM over all rows.  0: dense rows (tile t + 1 follows tile t).
+    int tile_stride;
 };
+
+// rows [r_begin, r_end) of a row-major [.. x W] array := 0 (all NT threads of the workgroup; W a multiple of 4)
+template <int NT>
+__device__ __forceinline__ void fz_clear_rows(float* p, int W, int r_begin, int r_end, int tid) {
+    if (p == nullptr) return;
+    const int w4 = W >> 2;
+    f32x4* q = (f32x4*)(p + (size_t)r_begin * W);
+    const int n = (r_end - r_begin) * w4;
+    for (int i = tid; i < n; i += NT) q[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
 
 // acc[nb][rb] += A(rows of this wave, K) . B_nb(K, 32 cols)   with A in LDS, B streamed from global.
 //   As_wave = &tile[(wave_row0 + (lane & 31)) * LD + 4 * (lane >> 5)]

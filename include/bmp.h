@@ -128,16 +128,20 @@ int bmp_gru_state_bwd(const float* dsout, const float* hd, const float* m, const
  * mt_row0 / mt_nblk (both NULL: tile t = rows [128 t, 128 t + 128)): the tile table of the encoder layout
  * (bmp_collate_plan_enc) -- tile t = rows [mt_row0[t], mt_row0[t] + 32 mt_nblk[t]), 1 <= mt_nblk <= 4; a tile's dead
  * blocks cost no gather, MFMA, load or store; mt_rows = the rows of the launch's tiles (the event timer's flop accounting,
- * ignored without a table).  m, rz, c may be NULL together (forward-only evaluation). */
+ * ignored without a table).  m, rz, c may be NULL together (forward-only evaluation).
+ * tile_stride (bmp_ggnn_step_fwd / _bwd; 0 or 128, 128 only with a table): 0 = dense rows, tile t + 1 follows tile t;
+ * 128 = the tiles sit at a fixed stride (a batch of a fixed shape whose step is recorded once as a HIP graph: one molecule
+ * per tile, mt_nblk its live blocks) and every launch CLEARS the rows of a tile's other blocks in the arrays it writes
+ * (hout, m, rz, c; dh, gda), so that nothing an earlier batch left there enters the GEMMs that walk all rows. */
 int bmp_ggnn_step_supported(int d);
 int bmp_ggnn_step_fwd(const float* h, int tile0, int n_tiles, int d, int first, const int* csr_ptr, const int* csr_col,
                       const float* csr_val, const float* WT, const float* bE, const float* AT, const float* UcT,
                       const float* b, float* m, float* rz, float* c, float* hout, const int* mt_row0, const int* mt_nblk,
-                      int mt_rows, bmp_stream_t stream);
+                      int mt_rows, int tile_stride, bmp_stream_t stream);
 int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float* rz, const float* c, int n_tiles, int d, int first,
                       const int* csrT_ptr, const int* csrT_col, const float* csrT_val, const float* Wnat, const float* A,
-                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, int skip_zero_g,
-                      bmp_stream_t stream);
+                      const float* Uc, float* dh, float* gda, const int* mt_row0, const int* mt_nblk, int mt_rows, int tile_stride,
+                      int skip_zero_g, bmp_stream_t stream);
 /* skip_zero_g != 0 (bmp_ggnn_step_bwd, bmp_relgcn_layer_bwd): the caller reads gda's per-type blocks through the batch's row lists
  * only -- it passes type_rows to the wgrad call and bmp_step_wgrad_lists_used(N, d) said the lists will be used -- so the block
  * of a row without a bond of the type, an exact zero, is not written. */

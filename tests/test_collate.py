@@ -153,3 +153,40 @@ def test_plan_equals_host_packer_on_random_stores():
             assert np.array_equal(v, getattr(ref, k).numpy()), k
 
     check()
+
+
+def test_one_molecule_per_tile_plan_holds_the_same_molecules():
+    """bmp.packed.plan_one_per_tile (the fixed-shape batch a recorded step replays on): the emit kernel's restatement, run on
+    that plan, writes every row of 2 B tiles, and every instance's rows, pad multiplicity and bonds are those of the usual
+    packed batch, shifted to the instance's own tile."""
+    R, B = 128, 24
+    store = synth.make_store(70, seed=21, n_lo=1, n_hi=100, n_mean=25)
+    ms = packed.MolStore(store)
+    ds = packed.DeviceMolStore(ms, "cpu")
+    rs = np.random.RandomState(4)
+    sides = [rs.randint(0, 70, B), rs.randint(0, 70, B)]
+    I = 2 * B
+    tab = np.zeros(6 * I, dtype=np.int32); mt = np.zeros(2 * I, dtype=np.int32)
+    I_, E, n_real = packed.plan_one_per_tile(ds.st_nrows, ds.st_nedges, sides, R, tab, mt)
+    ref = packed.pack_from_store(ms, sides)
+    assert (I_, E, n_real) == (I, ref.n_edges, ref.n_real_atoms)
+    assert np.array_equal(tab[I:2 * I], ref.mol_nrows.numpy())
+    assert np.array_equal(mt[:I], np.arange(I) * R) and np.array_equal(mt[I:], (tab[I:2 * I] + 31) // 32)
+    got = emit_numpy(ds, tab, I, I, E, R)
+    for k, v in got.items():
+        assert not (v == -7).any(), k                      # every element written (the dead rows through ndead)
+    r0, rr0, nr = tab[:I], ref.mol_row0.numpy(), ref.mol_nrows.numpy()
+    rw, rp, rc = ref.row_w.numpy(), ref.csr_ptr.numpy(), ref.csr_col.numpy()
+    for i in range(I):
+        a, b = slice(r0[i], r0[i] + nr[i]), slice(rr0[i], rr0[i] + nr[i])
+        assert np.array_equal(got["atom_id"][a], ref.atom_id.numpy()[b]) and np.array_equal(got["row_w"][a], rw[b])
+        assert (got["row_mol"][a] == i).all()
+        dead = slice(r0[i] + nr[i], r0[i] + R)
+        assert (got["row_w"][dead] == 0).all() and (got["row_mol"][dead] == -1).all()
+        assert (np.diff(got["csr_ptr"][r0[i] + nr[i]:r0[i] + R + 1]) == 0).all()          # dead rows: no bonds
+        for l in range(nr[i]):                                                             # the same bonds, other row numbers
+            mine = got["csr_col"][got["csr_ptr"][r0[i] + l]:got["csr_ptr"][r0[i] + l + 1]]
+            theirs = rc[rp[rr0[i] + l]:rp[rr0[i] + l + 1]]
+            assert np.array_equal(mine - (r0[i] << 2), theirs - (rr0[i] << 2))
+    with pytest.raises(ValueError):
+        packed.plan_one_per_tile(ds.st_nrows, ds.st_nedges, sides, 64, tab, mt)            # a 100-atom molecule, 64-row tiles

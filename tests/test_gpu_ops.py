@@ -456,7 +456,7 @@ def test_step_and_layer_forward_over_tile_ranges_equal_the_whole_launch(fn, batc
         m, rz, c, hout = f(N, d), f(N, 2 * d), f(N, d), f(N, d)
         for t0, nt in ranges:
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, 0, ptr(pbd.csr_ptr), ptr(pbd.csr_col), ptr(pbd.csr_val), ptr(WTp), ptr(bE),
-                                      ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout), None, None, 0, stream()), "step")
+                                      ptr(ATp), ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(hout), None, None, 0, 0, stream()), "step")
         return m, rz, c, hout
 
     def layer(ranges):

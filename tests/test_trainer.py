@@ -72,8 +72,9 @@ def test_pair_batches_share_every_global_batch_over_the_ranks(n, B, world):
 
 @pytest.mark.gpu
 def test_fit_from_the_store_in_either_layout_gives_the_same_run():
-    """PairBatches in the per-instance layout, in the encoder layout and with each distinct molecule encoded once: the same
-    losses and validation metrics epoch by epoch (different summation orders only)."""
+    """PairBatches in the per-instance layout, in the encoder layout, with each distinct molecule encoded once, and as replays
+    of one recorded HIP graph on a fixed-shape batch (layout="static"; the last batch of a pass is short and runs launch by
+    launch in between): the same losses and validation metrics epoch by epoch (different summation orders only)."""
     from bmp import packed, synth
     from bmp.dp import FlatAdam
     from bmp.predictor import build_pair_predictor
@@ -85,7 +86,8 @@ def test_fit_from_the_store_in_either_layout_gives_the_same_run():
     nat = np.array([m.n for m in store])
     lab = ((nat[i1] + nat[i2]) % 2).astype(np.int32).reshape(-1, 1)
     runs = {}
-    for name, kw in (("instance", {}), ("encoder", dict(layout="encoder")), ("dedup", dict(layout="encoder", dedup=True))):
+    for name, kw in (("instance", {}), ("encoder", dict(layout="encoder")), ("dedup", dict(layout="encoder", dedup=True)),
+                     ("static", dict(layout="static"))):
         torch.manual_seed(0)
         model = build_pair_predictor(hidden_dim=64, out_dim=32, n_layers=2, attn="nie", head=4).to(dev)
         opt = FlatAdam(model, alpha=2e-3)
@@ -93,7 +95,7 @@ def test_fit_from_the_store_in_either_layout_gives_the_same_run():
         va = T.PairBatches(ds, i1[256:], i2[256:], lab[256:], 48, **kw)
         assert len(tr) == 6 and len(va) == 2
         runs[name] = T.fit(model, opt, tr, va, epochs=3, eval_train=True)
-    for name in ("encoder", "dedup"):
+    for name in ("encoder", "dedup", "static"):
         for a, b in zip(runs["instance"], runs[name]):
             for key in ("main/loss", "validation/main/loss"):
                 assert abs(a[key] - b[key]) <= 2e-4 * abs(a[key]), (name, key, a[key], b[key])

@@ -37,7 +37,7 @@ for n_cu in (256,):
         nb = pb.mt_nblk.cpu().numpy() if pb.mt_nblk is not None else np.full(pb.n_tiles, 4)
         def run(t0, nt, first=0):
             check(L.bmp_ggnn_step_fwd(ptr(h), t0, nt, d, first, ptr(pb.csr_ptr), ptr(pb.csr_col), ptr(pb.csr_val), ptr(WTp), ptr(bE), ptr(ATp),
-                                      ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(ho), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, stream()), "f")
+                                      ptr(UcTp), ptr(b), ptr(m), ptr(rz), ptr(c), ptr(ho), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, 0, stream()), "f")
         T = pb.n_mtiles
         print(name, "tiles", T, "heights", np.bincount(nb), "rows", N)
         print("  all tiles          %7.1f us" % timeit(lambda: run(0, T)))
