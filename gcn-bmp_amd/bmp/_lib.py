@@ -42,9 +42,10 @@ SIGNATURES = {
     "bmp_ggnn_step_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I] + [_P] * 10 + [_I, _I, _I, _P]),
     "bmp_step_wgrad_lists_used": (_I, [_I, _I]),
     "bmp_ggnn_step_wgrad_ws_floats": (_Z, [_I, _I]),
-    "bmp_ggnn_step_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
+    "bmp_ggnn_step_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "bmp_type_rows_ws_ints": (_Z, [_I]),
     "bmp_type_rows": (_I, [_P, _P, _I, _P, _P, _P, _P]),
+    "bmp_type_rows_live": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "bmp_readout_tile_supported": (_I, [_I, _I, _I]),
     "bmp_readout_tile_fwd": (_I, [_P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "bmp_relgcn_layer_supported": (_I, [_I, _I]),

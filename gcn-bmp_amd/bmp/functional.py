@@ -315,7 +315,7 @@ class GGNNStepFn(Function):
         nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
         ws = _ws(nws, dev)
         check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(o1), ptr(o2), ptr(dUcT), ptr(cs),
-                                    acc, ptr(tri), ptr(trc), ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
+                                    acc, ptr(tri), ptr(trc), None, None, ptr(ws), nws, stream()), "bmp_ggnn_step_wgrad")
         if st is not None:
             st["seen"] += 1
             if st["seen"] < cache[("n",) + grp[1:]]:
@@ -664,6 +664,7 @@ class PStepFn(Function):
         dh = torch.empty(N, d, dtype=torch.float32, device=h.device)
         gda = torch.empty(N, 7 * d, dtype=torch.float32, device=h.device)
         tri, trc, skip = step_lists(pb, N, d)
+        lvi, lvc = pb._cache.get("live_rows", (None, None)) if tri is not None else (None, None)      # (a fixed-stride batch)
         check(L.bmp_ggnn_step_bwd(ptr(dhout), ptr(h), ptr(rz), ptr(c), pb.n_mtiles, d, first, ptr(pb.csrT_ptr),
                                   ptr(pb.csrT_col), ptr(pb.csrT_val), ptr(W["Wnat_p"]), ptr(W["A_p"]), ptr(W["Uc_p"]),
                                   ptr(dh), ptr(gda), ptr(pb.mt_row0), ptr(pb.mt_nblk), pb.n_rows, pb.tile_stride, skip, stream()), "bmp_ggnn_step_bwd")
@@ -673,7 +674,7 @@ class PStepFn(Function):
             nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
             ws = ws_of(nws, h.device)
             check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, first, ptr(G["o1"]), ptr(G["o2"]),
-                                        ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(tri), ptr(trc), ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
+                                        ptr(G["dUcT"]), ptr(G["cs"]), acc, ptr(tri), ptr(trc), ptr(lvi), ptr(lvc), ptr(ws), nws, st), "bmp_ggnn_step_wgrad")
 
         _on_side(ctx.state, (h, m, rz, gda), wgrad)
         return dh, None, None, None, None, None, None, None

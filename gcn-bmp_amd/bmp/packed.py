@@ -198,11 +198,18 @@ class PackedMolBatch:
             from ._lib import check, ptr, stream
             L = _lib.lib()
             N, dev = self.n_rows, self.atom_id.device
-            idx = torch.empty(4 * N, dtype=torch.int32, device=dev)
-            cnt = torch.empty(4, dtype=torch.int32, device=dev)
-            ws = torch.empty(max(int(L.bmp_type_rows_ws_ints(N)), 4), dtype=torch.int32, device=dev)
+            live = bool(self.tile_stride) and not forward and self.row_mol is not None
+            nl = 5 if live else 4
+            idx = torch.empty(nl * N, dtype=torch.int32, device=dev)
+            cnt = torch.empty(nl, dtype=torch.int32, device=dev)
+            ws = torch.empty(max(int(L.bmp_type_rows_ws_ints(N)), 8), dtype=torch.int32, device=dev)
             cp, cc = (self.csr_ptr, self.csr_col) if forward else (self.csrT_ptr, self.csrT_col)
-            check(L.bmp_type_rows(ptr(cp), ptr(cc), N, ptr(idx), ptr(cnt), ptr(ws), stream()), "bmp_type_rows")
+            if live:        # tiles at a fixed stride: most rows belong to no molecule, and a fifth list names those that do
+                check(L.bmp_type_rows_live(ptr(cp), ptr(cc), ptr(self.row_mol), N, ptr(idx), ptr(cnt), ptr(ws), stream()),
+                      "bmp_type_rows_live")
+                self._cache["live_rows"] = (idx[4 * N:], cnt[4:])
+            else:
+                check(L.bmp_type_rows(ptr(cp), ptr(cc), N, ptr(idx), ptr(cnt), ptr(ws), stream()), "bmp_type_rows")
             tr = (idx, cnt)
             self._cache[key] = tr
         return tr

@@ -794,7 +794,8 @@ extern "C" int bmp_ggnn_step_bwd(const float* dhout, const float* h, const float
 static const float kTypeFrac[4] = {0.78f, 0.24f, 0.05f, 0.58f};      // expected shares (single, double, triple, aromatic): balance only
 static int step_wgrad_problems(WGArgs* g, const float* h, const float* m, const float* rz, const float* gda, int N, int d,
                                int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate,
-                               const int* type_rows = nullptr, const int* type_cnt = nullptr) {
+                               const int* type_rows = nullptr, const int* type_cnt = nullptr, const int* live_rows = nullptr,
+                               const int* live_cnt = nullptr) {
     g[1] = WGArgs{m, nullptr, d, 0, gda + 4 * d, 7 * d, d, first ? 2 * d : 3 * d, N, o2, 3 * d, accumulate};
     g[2] = WGArgs{rz, h, 2 * d, d, gda + 6 * d, 7 * d, d, d, N, dUcT, d, accumulate};
     if (first) {
@@ -812,6 +813,10 @@ static int step_wgrad_problems(WGArgs* g, const float* h, const float* m, const 
         g[3 + e] = WGArgs{h, nullptr, d, 0, gda + e * d, 7 * d, d, d, N, o1 + e * d, 7 * d, accumulate, cs + e * d};
         g[3 + e].ridx = type_rows + (size_t)e * N; g[3 + e].rcnt = type_cnt + e; g[3 + e].rfrac = kTypeFrac[e];
     }
+    // a batch with few live rows (tiles at a fixed stride): the gate blocks through the list of the molecules' rows.  (Not the
+    // first call's form -- its skipped da_r columns and a list do not combine in the kernel -- nor dUcT's product operand.)
+    if (live_rows && live_cnt && !first)
+        for (int q = 0; q < 2; ++q) { g[q].ridx = live_rows; g[q].rcnt = live_cnt; g[q].rfrac = 0.3f; }
     return 7;
 }
 
@@ -834,6 +839,10 @@ extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
         n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0, (const int*)16, (const int*)16);
         b = bmp_wgrad_fused_ws_floats(g, n);
         if (b > a) a = b;
+        n = step_wgrad_problems(g, nullptr, nullptr, nullptr, nullptr, N, d, 0, nullptr, nullptr, nullptr, (float*)16, 0, (const int*)16, (const int*)16,
+                                (const int*)16, (const int*)16);
+        b = bmp_wgrad_fused_ws_floats(g, n);
+        if (b > a) a = b;
     }
     return a;
 }
@@ -849,8 +858,10 @@ extern "C" size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d) {
 // the rows that have a bond of the type only (the others' G_e rows are exact zeros: same sums, fewer products).
 extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d,
                                    int first, float* o1, float* o2, float* dUcT, float* cs, int accumulate,
-                                   const int* type_rows, const int* type_cnt, float* ws, size_t ws_floats, hipStream_t st) {
+                                   const int* type_rows, const int* type_cnt, const int* live_rows, const int* live_cnt,
+                                   float* ws, size_t ws_floats, hipStream_t st) {
     BMP_REQUIRE(N > 0 && d > 0 && ws_floats >= bmp_ggnn_step_wgrad_ws_floats(N, d));
+    BMP_REQUIRE((live_rows != nullptr) == (live_cnt != nullptr));
     BMP_REQUIRE(h && m && rz && gda && o1 && o2 && dUcT && cs && ws);
     static const bool unfused = getenv("BMP_STEP_WGRAD_UNFUSED") != nullptr;        // A/B switch (tools, tests)
     if (!unfused && d == 32 && (N & 7) == 0 && ((uintptr_t)gda & 15) == 0)          // one 32-row MFMA block per output: bmp_fused_small.hip
@@ -860,7 +871,7 @@ extern "C" int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* 
         WGArgs g[BMP_WG_MAXP];
         const bool lists = type_rows != nullptr && type_cnt != nullptr && bmp_wgrad_fused_lists_ok(N);
         const int n = step_wgrad_problems(g, h, m, rz, gda, N, d, first, o1, o2, dUcT, cs, accumulate, lists ? type_rows : nullptr,
-                                          lists ? type_cnt : nullptr);
+                                          lists ? type_cnt : nullptr, lists ? live_rows : nullptr, lists ? live_cnt : nullptr);
         return bmp_launch_wgrad_fused(g, n, ws, st, BMP_KID_WGRAD_STEP);
     }
     // one launch per product (first steps: the da_r columns of gda are not written, so they are zeroed here first)

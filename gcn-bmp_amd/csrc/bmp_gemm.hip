@@ -615,6 +615,11 @@ struct WGKArgs {
     const int* ridx = nullptr; const int* rcnt = nullptr; const float* zrow = nullptr; int nsplit = 0;
 };
 
+// 128 zero floats in device memory (zero-initialised when the code object is loaded, per device): what a listed problem of
+// the LDS-DMA body reads for the pieces past the end of its list.  (It used to be the head of the launch's workspace, cleared
+// by a memset of its own in front of every such launch: four 5 us launches per GGNN step.)
+__device__ float bmp_wg_zero_row[128];
+
 template <int MB, int NB>
 __global__ __launch_bounds__(256) void k_wgrad(WGKArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -922,7 +927,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WGKArgs& a, int want_cs, in
     typedef const __attribute__((address_space(4))) wd_v2i wd_cv2i;
     typedef const __attribute__((address_space(4))) int wd_cint;
     wd_cint* const ridx_ = IDX ? (wd_cint*)(uintptr_t)a.ridx : nullptr;
-    const float* const xb_ = a.X; const float* const yb_ = a.dY; const float* const zr_ = IDX ? a.zrow + 4 * l31 : nullptr;
+    const float* const xb_ = a.X; const float* const yb_ = a.dY; const float* const zr_ = IDX ? bmp_wg_zero_row + 4 * l31 : nullptr;
     const int ldx_ = a.ldx, ldy_ = a.ldy;
     const int cap_ = a.N;
     const int wu_ = __builtin_amdgcn_readfirstlane(w);
@@ -1470,8 +1475,8 @@ int bmp_launch_wgrad_fused(const WGArgs* a, int n, float* ws, hipStream_t st, in
         BMP_REQUIRE(!a[p].wrow || (a[p].cs && a[p].wout && a[p].skip_n == 0 && (a[p].w_col0 & 127) == 0));
     }
     wgrad_fused_plan(a, n, m.S, rps, m.ty0);
-    float* zrow = ws;                                // 128 zero floats: what a listed problem reads past the end of its list
-    if (listed) { hipError_t e = hipMemsetAsync(zrow, 0, 128 * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+    float* zrow = ws;                                // (the first 128 floats stay unused: bmp_wgrad_fused_ws_floats counts them)
+    (void)listed;
     size_t off = 128;
     int smax = 0, rb = 0;
     double flops = 0, bytes = 0;

@@ -212,69 +212,91 @@ extern "C" int bmp_embed_bwd(const int* ids, const float* dout, int N, int d, in
 //   pass 1: per 256-row block and type, the number of such rows;  pass 2: every block sums the counts of the blocks in
 //   front of it (at most N / 256 of them) and writes its rows at their ranks.  Fixed order, no atomics.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tr_mask(const int* __restrict__ ptr, const int* __restrict__ col, int row, int N) {
+__device__ __forceinline__ int tr_mask(const int* __restrict__ ptr, const int* __restrict__ col, const int* __restrict__ row_mol,
+                                       int row, int N) {
     int m = 0;
-    if (row < N)
+    if (row < N) {
         for (int e = ptr[row]; e < ptr[row + 1]; ++e) m |= 1 << (col[e] & 3);
+        if (row_mol && row_mol[row] >= 0) m |= 16;          // list 4: the rows of a molecule (real atoms and pad rows)
+    }
     return m;
 }
-__global__ __launch_bounds__(256) void k_type_rows_count(const int* __restrict__ ptr, const int* __restrict__ col, int N, int* __restrict__ bcnt) {
-    __shared__ int wc[4][4];
+template <int NE>
+__global__ __launch_bounds__(256) void k_type_rows_count(const int* __restrict__ ptr, const int* __restrict__ col,
+                                                         const int* __restrict__ row_mol, int N, int* __restrict__ bcnt) {
+    __shared__ int wc[4][NE];
     const int row = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int m = tr_mask(ptr, col, row, N);
+    const int m = tr_mask(ptr, col, row_mol, row, N);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int c = __popcll(__ballot((m >> e) & 1));
         if (lane == 0) wc[w][e] = c;
     }
     __syncthreads();
-    if (threadIdx.x < 4) bcnt[blockIdx.x * 4 + threadIdx.x] = wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x];
+    if (threadIdx.x < NE) bcnt[blockIdx.x * NE + threadIdx.x] = wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x];
 }
-__global__ __launch_bounds__(256) void k_type_rows_emit(const int* __restrict__ ptr, const int* __restrict__ col, int N, const int* __restrict__ bcnt,
+template <int NE>
+__global__ __launch_bounds__(256) void k_type_rows_emit(const int* __restrict__ ptr, const int* __restrict__ col,
+                                                        const int* __restrict__ row_mol, int N, const int* __restrict__ bcnt,
                                                         int* __restrict__ idx, int* __restrict__ cnt) {
-    __shared__ int base[4], wc[4][4], red[4][4];
+    __shared__ int base[NE], wc[4][NE], red[4][NE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = blockIdx.x * 256 + tid;
     // offsets of this block: the counts of the blocks in front of it, summed in a fixed order
-    int part[4] = {0, 0, 0, 0};
+    int part[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) part[e] = 0;
     for (int b = tid; b < (int)blockIdx.x; b += 256)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[e] += bcnt[b * 4 + e];
+        for (int e = 0; e < NE; ++e) part[e] += bcnt[b * NE + e];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         int v = part[e];
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
         if (lane == 0) red[w][e] = v;
     }
-    const int m = tr_mask(ptr, col, row, N);
-    unsigned long long bal[4];
+    const int m = tr_mask(ptr, col, row_mol, row, N);
+    unsigned long long bal[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         bal[e] = __ballot((m >> e) & 1);
         if (lane == 0) wc[w][e] = __popcll(bal[e]);
     }
     __syncthreads();
-    if (tid < 4) base[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < NE) base[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < NE; ++e) {
         int off = base[e];
         for (int q = 0; q < w; ++q) off += wc[q][e];
         if ((m >> e) & 1) idx[(size_t)e * N + off + __popcll(bal[e] & ((1ull << lane) - 1ull))] = row;
     }
-    if (blockIdx.x == gridDim.x - 1 && tid < 4) cnt[tid] = base[tid] + wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+    if (blockIdx.x == gridDim.x - 1 && tid < NE) cnt[tid] = base[tid] + wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
 }
 
 // idx [4 x N] int32, cnt [4] int32; ws: bmp_type_rows_ws_ints(N) ints.  ptr / col: the CSR whose gather the lists describe (the
 // TRANSPOSED CSR for the backward's gathered gradients G_e).
-extern "C" size_t bmp_type_rows_ws_ints(int N) { return (size_t)((N + 255) / 256) * 4; }
+extern "C" size_t bmp_type_rows_ws_ints(int N) { return (size_t)((N + 255) / 256) * 8; }
 extern "C" int bmp_type_rows(const int* csr_ptr, const int* csr_col, int N, int* idx, int* cnt, int* ws, hipStream_t st) {
     BMP_REQUIRE(csr_ptr && N > 0 && idx && cnt && ws);          // (csr_col may be NULL: a batch without a single bond)
     const int nb = (N + 255) / 256;
-    hipLaunchKernelGGL(k_type_rows_count, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, N, ws);
+    hipLaunchKernelGGL(k_type_rows_count<4>, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, (const int*)nullptr, N, ws);
     BMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_type_rows_emit, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, N, ws, idx, cnt);
+    hipLaunchKernelGGL(k_type_rows_emit<4>, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, (const int*)nullptr, N, ws, idx, cnt);
+    BMP_LAUNCH_CHECK();
+    return 0;
+}
+// The same with a FIFTH list: the rows that belong to a molecule (row_mol >= 0: real atoms and pad rows), ascending -- idx
+// [5 x N], cnt [5].  For a batch whose tiles sit at a fixed stride (one molecule per tile: three rows of four belong to no
+// molecule) the step's weight-gradient launch walks that list instead of all N rows (bmp_ggnn_step_wgrad: live_rows).
+extern "C" int bmp_type_rows_live(const int* csr_ptr, const int* csr_col, const int* row_mol, int N, int* idx, int* cnt, int* ws,
+                                  hipStream_t st) {
+    BMP_REQUIRE(csr_ptr && row_mol && N > 0 && idx && cnt && ws);
+    const int nb = (N + 255) / 256;
+    hipLaunchKernelGGL(k_type_rows_count<5>, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, row_mol, N, ws);
+    BMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_type_rows_emit<5>, dim3(nb), dim3(256), 0, st, csr_ptr, csr_col, row_mol, N, ws, idx, cnt);
     BMP_LAUNCH_CHECK();
     return 0;
 }

@@ -149,16 +149,22 @@ int bmp_step_wgrad_lists_used(int N, int d);
 size_t bmp_ggnn_step_wgrad_ws_floats(int N, int d);
 /* type_rows [4 x N] / type_cnt [4] (both optional, NULL together): bmp_type_rows of the batch's TRANSPOSED CSR.  A row's
  * gathered gradient G_e is an exact zero unless the row has a bond of type e (73 / 19 / 2 / 52 % of the rows of a DDI batch for
- * single / double / triple / aromatic): with the lists the four per-type blocks of o1 sum over their rows only. */
+ * single / double / triple / aromatic): with the lists the four per-type blocks of o1 sum over their rows only.
+ * live_rows / live_cnt (optional, NULL together; used with type_rows): the fifth list of bmp_type_rows_live, the rows that
+ * belong to a molecule -- for a batch most of whose rows belong to none (tiles at a fixed stride) the gate blocks of o1 and o2
+ * sum over that list instead of all N rows (later calls only; the other rows' gda is zero either way). */
 int bmp_ggnn_step_wgrad(const float* h, const float* m, const float* rz, const float* gda, int N, int d, int first,
                         float* o1, float* o2, float* dUcT, float* cs, int accumulate, const int* type_rows, const int* type_cnt,
-                        float* ws, size_t ws_floats, bmp_stream_t stream);
+                        const int* live_rows, const int* live_cnt, float* ws, size_t ws_floats, bmp_stream_t stream);
 
 /* Rows by bond type of a CSR (no reference counterpart: the reference's dense (mb, 4, A, A) adjacency multiplies the zeros,
  * models/ggnn.py:229-242): idx[e * N + p] = the p-th row, ascending, that holds an entry of type e; cnt[e] = their number
  * (device arrays; the count never visits the host).  ws: bmp_type_rows_ws_ints(N) ints.  Fixed order, no atomics. */
 size_t bmp_type_rows_ws_ints(int N);
 int bmp_type_rows(const int* csr_ptr, const int* csr_col, int N, int* idx, int* cnt, int* ws, bmp_stream_t stream);
+/* The same with a fifth list, idx [5 x N] / cnt [5]: list 4 = the rows that belong to a molecule (row_mol >= 0), ascending. */
+int bmp_type_rows_live(const int* csr_ptr, const int* csr_col, const int* row_mol, int N, int* idx, int* cnt, int* ws,
+                       bmp_stream_t stream);
 
 /* One whole RelGCN layer, fused per 128-row tile -- RelGCNUpdate.__call__ models/update/relgcn_update.py:24-44 with
  * the tanh of models/relgcn.py:71: out = act(h W_s^T + b_s + sum_e adj'_e (W_e h + b_e)), the 1/degree of rescale_adj

@@ -76,7 +76,7 @@ def test_one_graph_replays_every_batch(world, name):
         loss = oe.functional_loss(pb, t=t); loss.backward(); oe.collect_grads(); oe.step()
         le.append(float(loss.detach()))
         sb.load([i1[sl], i2[sl]], lab[sl])
-        lg.append(float(stepper(sb)))
+        lg.append(float(stepper(sb).detach()))
     assert len(stepper.graphs) == 1 and og.t == oe.t == steps
     close(torch.tensor(lg), torch.tensor(le), f"graph on the static batch {name}: losses of {steps} steps", tol=1e-4)
     close(og.flat, oe.flat, f"graph on the static batch {name}: parameters after {steps} steps", tol=1e-4)

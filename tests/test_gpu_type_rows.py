@@ -70,7 +70,7 @@ def test_step_wgrad_with_row_lists_equals_all_rows(d, first):
         ws = torch.empty(nws, device=dev)
         for acc in (0, 1):                   # written, then accumulated into (tied layers): twice the sums
             check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, int(first), ptr(o1), ptr(o2), ptr(dU), ptr(cs), acc,
-                                        ptr(idx if lists else None), ptr(cnt if lists else None), ptr(ws), nws, stream()), "wgrad")
+                                        ptr(idx if lists else None), ptr(cnt if lists else None), None, None, ptr(ws), nws, stream()), "wgrad")
         torch.cuda.synchronize()
         out.append((o1.clone(), o2.clone(), dU.clone(), cs.clone()))
     ref = 2.0 * (h.double().t() @ gda.double())
@@ -80,6 +80,56 @@ def test_step_wgrad_with_row_lists_equals_all_rows(d, first):
     for name, a_, b_ in zip(("o1", "o2", "dUcT", "cs"), out[0], out[1]):
         close(b_, a_.double(), f"{name} with lists vs all rows", tol=2e-5, floor=1e-3 * float(a_.abs().max()) + 1e-12)
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])       # o2 / dUcT: the same products in the same order
+
+
+@pytest.mark.parametrize("first", [True, False])
+def test_step_wgrad_over_the_live_rows_of_a_fixed_stride_batch(first):
+    """A batch with one molecule per 128-row tile (bmp.packed.StaticPairBatch): bmp_type_rows_live's fifth list names the rows
+    of a molecule, the step's weight-gradient launch walks it for the gate blocks -- the same o1 / o2 / dUcT / cs as the launch
+    over all rows, whose other rows hold zeros in gda."""
+    from bmp import _lib, packed, synth
+    from bmp._lib import check, ptr, stream
+    from parity_util import close
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    store = synth.make_store(60, seed=4, n_lo=2, n_hi=100, n_mean=22)
+    ds = packed.DeviceMolStore(packed.MolStore(store), dev)
+    rs = np.random.RandomState(2)
+    sb = packed.StaticPairBatch(ds, 24)
+    sb.load([rs.randint(0, 60, 24), rs.randint(0, 60, 24)], np.zeros((24, 1), np.int32)); sb.emit()
+    pb = sb.pb
+    N, d = pb.n_rows, 128
+    idx, cnt = pb.type_rows_T()
+    lvi, lvc = pb._cache["live_rows"]
+    torch.cuda.synchronize()
+    rm = pb.row_mol.cpu().numpy()
+    assert int(lvc[0]) == int((rm >= 0).sum()) and np.array_equal(lvi[:int(lvc[0])].cpu().numpy(), np.nonzero(rm >= 0)[0])
+    assert int(lvc[0]) < N // 2                                   # most rows belong to no molecule
+    g = torch.Generator().manual_seed(3 + int(first))
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    live = torch.from_numpy((rm >= 0).astype(np.float32)).to(dev)[:, None]
+    h, m, rz = rnd(N, d), rnd(N, d), torch.rand(N, 2 * d, generator=g).to(dev)
+    gda = rnd(N, 7 * d) * 1e-2 * live                             # what the backward leaves: zeros in the rows of no molecule
+    mask = torch.zeros(4, N, device=dev)
+    for e in range(4):
+        mask[e, idx[e * N: e * N + int(cnt[e])].long()] = 1.0
+        gda[:, e * d:(e + 1) * d] *= mask[e][:, None]
+    out = []
+    for use_live in (False, True):
+        o1, o2, dU, cs = (torch.full(s_, 7.0, device=dev) for s_ in ((d, 7 * d), (d, 3 * d), (d, d), (7 * d,)))
+        nws = L.bmp_ggnn_step_wgrad_ws_floats(N, d)
+        ws = torch.empty(nws, device=dev)
+        check(L.bmp_ggnn_step_wgrad(ptr(h), ptr(m), ptr(rz), ptr(gda), N, d, int(first), ptr(o1), ptr(o2), ptr(dU), ptr(cs), 0,
+                                    ptr(idx), ptr(cnt), ptr(lvi if use_live else None), ptr(lvc if use_live else None), ptr(ws), nws,
+                                    stream()), "wgrad")
+        torch.cuda.synchronize()
+        out.append((o1.clone(), o2.clone(), dU.clone(), cs.clone()))
+    ref = h.double().t() @ gda.double()
+    if first:
+        ref[:, 4 * d:5 * d] = 0.0
+    close(out[1][0], ref, f"o1 over the live rows vs float64 (first {first})", tol=2e-5)
+    for name, a_, b_ in zip(("o1", "o2", "dUcT", "cs"), out[0], out[1]):
+        close(b_, a_.double(), f"{name} over the live rows vs all rows", tol=2e-5, floor=1e-3 * float(a_.abs().max()) + 1e-12)
 
 
 def test_lists_off_switch_reaches_the_library():
