@@ -13,8 +13,11 @@
  *     (kernel, device) pairs already had hipFuncAttributeMaxDynamicSharedMemorySize raised
  *     (lock-free, per device: one process may drive several devices, from several host threads);
  *     (ii) A/B switches read once from the environment (BMP_WGRAD_DMA, BMP_WGRAD_XCD,
- *     BMP_STEP_WGRAD_UNFUSED, BMP_ROWGEMM_FORM / _DIRECT: diagnostics of tools/ and tests/);
- *     (iii) the opt-in event timer bmp_prof_*.  None of them changes a result.
+ *     BMP_STEP_WGRAD_UNFUSED, BMP_ROWGEMM_FORM / _DIRECT: diagnostics of tools/ and tests/,
+ *     BMP_ROWGEMM_NO_THIN);
+ *     (iii) the opt-in event timer bmp_prof_*.  None of them changes a result.  The code object
+ *     also holds one read-only device array of 128 zero floats (what a listed weight-gradient
+ *     problem reads past the end of its list).
  *   - row-indexed arrays use the packed layout of bmp/packed.py: N = n_tiles * bmp_tile_rows()
  *     rows (128 per tile, molecules never straddle a tile, dead rows are zero-weight).
  *   - weights come in two layouts: "T" = K-major [in x out] (used as the GEMM B operand) and
