@@ -479,19 +479,22 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
 // Up to three independent row GEMMs (generic epilogue) in one launch: x-blocks [bx0[p], bx0[p+1]) belong to problem p.  The
 // co-attention's projections are 228 tiles each -- alone, every one of them lasts one workgroup's latency.
 // A problem whose last column tile holds at most 32 columns (the co-attention's Z = J | P | v: 128 + 16) is cut in two by the
-// launcher: the whole 128-column tiles, and a THIN problem of the remainder that takes 128-row workgroups of ONE 32-column
-// block (each wave 32 rows).  As a second column tile the remainder kept one wave of four busy in a workgroup that staged
-// its rows and lasted as long as a full one: 910 of the 3190 workgroups of that launch.
+// launcher: the whole 128-column tiles, and a THIN problem of the remainder whose 64-row workgroups are 2 x 2 waves of 32 rows
+// x 32 columns (the waves of the second column block idle): half the MFMAs per wave of a full workgroup's, at the same
+// register and LDS footprint (a 128-row x 32-column form took the kernel from four to three waves per SIMD and the launch
+// from 57 to 73 us in line).  As a second column tile the remainder kept one wave of four busy in a workgroup that lasted as
+// long as a full one: 910 of the 3190 workgroups of that launch.  Measured: 116 against 118.5 us per C2 step -- the launch is
+// bound by its rounds of 64-row workgroups, not by the idle waves.
 #define RGM_MAXP 6
 struct RGMulti { RGArgs p[RGM_MAXP]; int bx0[RGM_MAXP + 1]; int ny[RGM_MAXP]; int thin[RGM_MAXP]; };
 __global__ __launch_bounds__(256) void k_rowgemm_multi(RGMulti m) {
-    __shared__ __attribute__((aligned(16))) float lds[BMP_R * BMP_LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[(BMP_R / 2) * BMP_LDS_LD];
     const int bx = blockIdx.x;
     int p = 0;
 #pragma unroll
     for (int q = 1; q < RGM_MAXP; ++q) p += bx >= m.bx0[q] ? 1 : 0;
     if ((int)blockIdx.y >= m.ny[p]) return;
-    if (m.thin[p]) rowgemm_body<4, 1, 1, BMP_EPI_GENERIC>(m.p[p], bx - m.bx0[p], 0, lds);              // 128 rows x 32 columns
+    if (m.thin[p]) rowgemm_body<2, 1, 1, BMP_EPI_GENERIC>(m.p[p], bx - m.bx0[p], 0, lds);              // 64 rows x (32 | idle) columns
     else rowgemm_body<1, 2, 1, BMP_EPI_GENERIC>(m.p[p], bx - m.bx0[p], blockIdx.y, lds);      // 64-row workgroups: two per tile
 }
 
@@ -587,7 +590,7 @@ int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStre
         ++np;
     }
     int blocks = 0;
-    for (int q = 0; q < np; ++q) { m.bx0[q] = blocks; blocks += m.thin[q] ? nt_of[q] : 2 * nt_of[q]; }
+    for (int q = 0; q < np; ++q) { m.bx0[q] = blocks; blocks += 2 * nt_of[q]; }
     for (int q = np; q <= RGM_MAXP; ++q) m.bx0[q] = blocks;
     for (int q = np; q < RGM_MAXP; ++q) m.bx0[q] = 0x7fffffff;      // (the kernel's search never lands behind the last problem)
     m.bx0[RGM_MAXP] = blocks;
