@@ -968,6 +968,9 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
     if (!st_w) st_w = st;
     {
         const int cnt[4] = {n32, n64, n96, n128};
+        // (The 32-row class's pairs inside the 64-row class's launch -- one launch of 995 workgroups at 512 threads instead of
+        //  575 at 256 and 420 at 512 one after the other -- measured no faster: C2 400.2 / 398.2 against 401.2 / 400.6 k pairs/s,
+        //  C3 821 against 827 k.)
         // A size class of a few pairs is a launch of one workgroup's latency on an all but empty device: with a second stream
         // at hand (stream_w) the smallest such class runs there, beside the others, and `st` picks up behind it below.
         const int beside = co_beside_classes(cnt, st, st_w);       // bit c: class c runs on st_w
