@@ -305,6 +305,10 @@ class GraphedTrainStep:
         serves every batch loaded into it."""
         static = pb if callable(getattr(pb, "emit", None)) else None
         if static is not None:
+            if self.opt.world > 1:
+                # (one rank per GPU records its own step; the all-reduce inside a recording has never run on this stack)
+                raise NotImplementedError("a step recorded on a fixed-shape batch is a single-rank path here: the RCCL all-reduce "
+                                          "inside a HIP graph is untested; use the packed layouts for N > 1")
             pb, t = static.pb, static.t
         key = (id(pb), id(t))
         o = self.opt

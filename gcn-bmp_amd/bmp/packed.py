@@ -789,6 +789,8 @@ class StaticPairBatch:
         if rc:
             raise RuntimeError(f"bmp_collate_pair_meta failed ({rc})")
         st[self.n_tab + self.n_meta + self.n_mt:] = lab
+        # (host copy of the row counts: what the operators outside the recorded path read -- the coarse co-attention family)
+        self.pb.mol_nrows_host = st[I:2 * I].astype(np.int64)
         self.dstore.plan_seconds += _time.perf_counter() - t0
         self.dstore.plan_calls += 1
         self.up.copy_(self._stage[k], non_blocking=True)
