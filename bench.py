@@ -350,7 +350,15 @@ def main():
             for i in range(warmup):
                 body(i)
             dt, every = timed(steps, lambda i: body(warmup + i))
-            return self.gb * steps / dt, dt, every, float(last["loss"].item())
+            loss = float(last["loss"].item())
+            # the host's own time per step: three steps issued into empty queues (nothing to wait for), untimed by the leg
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3):
+                body(i)
+            self.host_ms_per_step = round(1e3 * (time.perf_counter() - t0) / 3, 3)
+            torch.cuda.synchronize()
+            return self.gb * steps / dt, dt, every, loss
 
         def whole(self, value):
             return dict(alg_mflop_per_pair=round(self.alg_f / 1e6, 1), alg_kb_per_pair=round(self.alg_b / 1e3, 1),
@@ -470,6 +478,7 @@ def main():
 
     # ---- resident leg (the metric): packed batches already in HBM ---------------------------------------
     value, dt, every, loss_val = env.resident(args.steps, args.warmup)
+    env_main_host_ms = env.host_ms_per_step       # what the host needs to issue one step (measured into empty queues, outside the timed region)
     rank_ms = None if world == 1 else dict(min=round(1e3 * min(every) / args.steps, 3), max=round(1e3 * max(every) / args.steps, 3))
 
     # ---- end-to-end leg: one epoch, fresh permutation, collate inside the timed region --------------------
@@ -587,6 +596,7 @@ def main():
             v, dt_o, _, loss_o = e.resident(20, 4)
             r = e.roofline()
             others[name] = dict(value=round(v, 1), unit="pairs/s", ms_per_step=round(1e3 * dt_o / 20, 3), steps=20, warmup=4,
+                                host_ms_per_step=e.host_ms_per_step,
                                 whole_step=e.whole(v), loss=round(loss_o, 5), workload=e.cfg["workload"],
                                 dominant_kernel=None if r is None else dict(kernel=r["kernel"], frac=r["frac"], achieved=r["achieved"],
                                                                             avg_launch_us=r["avg_launch_us"], traffic=r["traffic"],
@@ -657,6 +667,7 @@ def main():
                        "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": gb, "parallelism": f"dp{world}",
                        "atoms_per_pair": round(atoms_per_pair_main, 2), "real_row_fraction": round(real_row_fraction_main, 4),
                        "loss": round(loss_val, 5)},
+            "host_ms_per_step": env_main_host_ms,
             "roofline": roof, "whole_step": whole, "end_to_end": e2e, "batch32": b32, "predict": pred, "dedup": dedup, "other_configs": others,
             "ref_headline": ref_head, "cpu_baseline": cpu}
         if cpu_more:

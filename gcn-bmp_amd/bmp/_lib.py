@@ -154,7 +154,8 @@ def check(rc: int, name: str) -> None:
 
 
 def ptr(t: torch.Tensor | None):
-    return None if t is None else c_void_p(t.data_ptr())
+    """Device address for a ``c_void_p`` argument (a plain int: ctypes converts it, and a step makes ~180 of these calls)."""
+    return None if t is None else t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -407,13 +407,19 @@ class GGNN(nn.Module):
         infer = not torch.is_grad_enabled()      # predict under no-backprop: nothing is kept for a backward
         bufs = [Fn.step_buffers(h.shape[0], self.hidden_dim, h.device, infer) for _ in range(self.n_layers)]
         Fn.fork_parts(state, pb)
-        per_step = []
-        for step, (li, mode) in enumerate(self._step_groups()):
-            W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
-                     b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])
-            g = f"g{li}_{mode}"
-            Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
-            per_step.append((W, Gs, g, step == 0))
+        # (the per-step operand dictionaries are views of the plan's two buffers: built once per plan, not once per step)
+        per_step = getattr(self, "_per_step", None)
+        if per_step is None or per_step[0] is not P:
+            lst = []
+            for step, (li, mode) in enumerate(self._step_groups()):
+                W = dict(WTp=P[f"msg{li}.WTp"], bE=P[f"msg{li}.bE"], Wnat_p=P[f"msg{li}.Wnat_p"], ATp=P[f"gru_{mode}.ATp"],
+                         b=P[f"gru_{mode}.b"], A_p=P[f"gru_{mode}.A_p"], UcTp=P["gru.UcTp"], Uc_p=P["gru.Uc_p"])
+                g = f"g{li}_{mode}"
+                Gs = dict(o1=G[g + ".o1"], o2=G[g + ".o2"], dUcT=G[g + ".dUcT"], cs=G[g + ".cs"])
+                lst.append((W, Gs, g, step == 0))
+            per_step = (P, lst)
+            object.__setattr__(self, "_per_step", per_step)
+        per_step = per_step[1]
         for step, (W, Gs, g, first) in enumerate(per_step):
             h = Fn.PStepFn.apply(h, pb, W, Gs, state, g, first, bufs[step])
         Fn._join_parts(state)                 # the steps ran as two chains of tiles: whole arrays are read from here on
