@@ -982,6 +982,8 @@ extern "C" int bmp_coattn_nie_bwd(const float* dout1, const float* dout2, const 
             a.np = 32 * (c + 1); a.ldc = a.np + 1; a.order_off = off;
             // threads per pair by size class: a launch lasts about one workgroup's latency, so bigger pairs get more
             // waves (np = 128 stays at 256: its per-thread partial-sum slots alias arrays sized for 256 threads)
+            // (the 32-row class at 512 / 1024 threads per pair: its 575 workgroups then take 0.167 / 0.191 ms per step of the
+            //  backward's pair kernels instead of 0.156: that launch is bound by the workgroups' resources, not their latency)
             const int nt = c == 0 ? 256 : (c == 1 ? 512 : (c == 2 ? CO_NT_BIG : 256));
             const size_t lds = co_lds_floats(a.np, a.ldc, H, true, o, nt) * sizeof(float);
             BMP_REQUIRE(lds <= 160 * 1024);
