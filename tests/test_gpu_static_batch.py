@@ -81,3 +81,60 @@ def test_one_graph_replays_every_batch(world, name):
     close(torch.tensor(lg), torch.tensor(le), f"graph on the static batch {name}: losses of {steps} steps", tol=1e-4)
     close(og.flat, oe.flat, f"graph on the static batch {name}: parameters after {steps} steps", tol=1e-4)
     assert not np.allclose(le[0], le[-1])          # (different batches: the losses move)
+
+
+@pytest.mark.parametrize("name", ["c2", "ref_ntn"])
+def test_recorded_step_matches_the_oracle(name):
+    """What `batch32` of bench.py times -- StaticPairBatch.load + ONE replay of the recorded step (emit, forward, loss, backward,
+    weight gradients, Adam) -- against the dense float64 oracle directly: loss, the flat gradient (every parameter) at 2e-5 and
+    the update of oracle.chainer_adam_step, for the C2 model and for the reference's published model (NTN), 32 pairs with
+    ignored labels.  The replay under test is the SECOND use of the recording (another batch went through the arrays first)."""
+    from bmp.dp import FlatAdam, GraphedTrainStep
+    from bmp.predictor import build_pair_predictor
+    from bmp.snapshot import load_param_dict
+    from oracle import ref_cpu as O
+    from test_gpu_planned_oracle import _oracle_step
+    T = torch.from_numpy
+    store = synth.make_store(60, seed=23, n_lo=3, n_hi=100, n_mean=22)
+    ds = packed.DeviceMolStore(packed.MolStore(store), dev())
+    rs = np.random.RandomState(8)
+    B = 32
+    first = (rs.randint(0, 60, B), rs.randint(0, 60, B), rs.randint(0, 2, (B, 1)).astype(np.int32))
+    i1, i2 = rs.randint(0, 60, B), rs.randint(0, 60, B)
+    lab = rs.randint(0, 2, (B, 1)).astype(np.int32)
+    lab[::9] = -1
+    a1, j1 = synth.concat_mols([store[k] for k in i1]); a2, j2 = synth.concat_mols([store[k] for k in i2])
+    if name == "c2":
+        kw, okw = dict(hidden_dim=128, out_dim=128, n_layers=4, attn="nie", head=8), {}
+    else:
+        kw = dict(hidden_dim=32, out_dim=16, n_layers=8, weight_tying=False, attn="nie", head=8, sim_method="ntn", mlp_hidden=())
+        okw = dict(weight_tying=False, sim_method="ntn", mlp_hidden=0)
+    p = O.make_pair_params(777, encoder="ggnn", dtype=torch.float64, bias_scale=0.05, **kw)
+    alpha = 1e-2
+    y_o, loss_o, g_o, p_o = _oracle_step(p, (a1, j1, a2, j2, lab), "ggnn", kw["n_layers"], "nie", alpha, **okw)
+
+    model = build_pair_predictor(encoder="ggnn", **kw).to(dev())
+    load_param_dict(model, p)
+    opt = FlatAdam(model, alpha=alpha)
+    flat0 = opt.flat.clone()
+    sb = packed.StaticPairBatch(ds, B)
+    stepper = GraphedTrainStep(model, opt)
+    sb.load([first[0], first[1]], first[2])
+    stepper(sb)                                           # records, replays once on another batch
+    opt.flat.copy_(flat0); opt.m.zero_(); opt.v.zero_(); opt.t = 0      # back to the oracle's starting point
+    sb.load([i1, i2], lab)
+    loss = stepper(sb)
+    close(loss.detach().reshape(1), loss_o.reshape(1), f"recorded step {name}: loss", tol=2e-5)
+    off = 0
+    for pname, shp in zip(opt.names, opt.shapes):
+        n = int(np.prod(shp))
+        key = pname.replace(".", "/")
+        ref = g_o[key]
+        if float(ref.abs().max()) > 0:                    # (readout parameters: the fine family ignores g_1 / g_2)
+            close(opt.grad[off:off + n].view(shp), ref, f"recorded step {name}: grad {pname}", tol=2e-5)
+        upd_o = p_o[key] - p[key]
+        upd = opt.flat[off:off + n].view(shp).double().cpu() - p[key].float().double()
+        big = ref.abs() > 1e-3 * ref.abs().max().clamp(min=1e-30)
+        if big.any():
+            assert (upd - upd_o)[big].abs().max().item() <= 1e-3 * alpha, pname
+        off += n
