@@ -20,6 +20,10 @@ __device__ __forceinline__ RGCol rg_col(const RGArgs& a, int col) {
 
 template <int EPI>
 __device__ __forceinline__ void rg_epilogue(const RGArgs& a, const RGCol& cc, int row, int col, float v) {
+#ifdef BMP_PROBE_NO_EPILOGUE       /* timing probe only (tools/build_variant.sh): one store per 16 accumulator registers */
+    if ((row & 15) == 0 && v == 12345.678f) a.Y[(size_t)row * a.ldy + col] = v;
+    return;
+#endif
     v += cc.bias;
     if (EPI == BMP_EPI_GENERIC) {
         if (a.wdeg) {
@@ -51,6 +55,66 @@ __device__ __forceinline__ void rg_epilogue(const RGArgs& a, const RGCol& cc, in
         float* o = a.o1 + (size_t)row * a.ldo1 + col;
         *o += v * r;
     }
+}
+
+// The same epilogues on FOUR consecutive columns of one row (col a multiple of 4): 16-byte loads and stores, a wave
+// instruction moves whole 512-byte rows.  The caller has checked the operands' strides and alignment (rg_vec_ok).
+struct RGCol4 { f32x4 bias; f32x4 bE[4]; };
+__device__ __forceinline__ RGCol4 rg_col4(const RGArgs& a, int col) {
+    RGCol4 c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c.bias[j] = a.bias ? a.bias[col + j] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c.bE[e][j] = a.wdeg ? a.bE[(size_t)e * a.ldbE + col + j] : 0.f;
+    }
+    return c;
+}
+template <int EPI>
+__device__ __forceinline__ void rg_epilogue4(const RGArgs& a, const RGCol4& cc, int row, int col, f32x4 v) {
+    v += cc.bias;
+    if (EPI == BMP_EPI_GENERIC) {
+        if (a.wdeg) {
+            const f32x4 wd = *(const f32x4*)(a.wdeg + (size_t)row * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v += wd[e] * cc.bE[e];
+        }
+        const bool lo = (a.split <= 0) || (col < a.split);
+        if (a.add && lo) v += *(const f32x4*)(a.add + (size_t)row * a.ldadd + col);
+        const int act = lo ? a.act_lo : a.act_hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bmp_act(act, v[j]);
+        if (!lo && a.o1) {
+            *(f32x4*)(a.o1 + (size_t)row * a.ldo1 + (col - a.split)) = v;
+        } else {
+            f32x4* y = (f32x4*)(a.Y + (size_t)row * a.ldy + col);
+            *y = a.accumulate ? (*y + v) : v;
+        }
+    } else if (EPI == BMP_EPI_GRU_OUT) {
+        f32x4 c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = bmp_tanh(v[j]);
+        const f32x4 z = *(const f32x4*)(a.z + (size_t)row * a.ldz + col);
+        *(f32x4*)(a.c_out + (size_t)row * a.ldc + col) = c;
+        f32x4 hn = z * c;
+        if (!a.first) hn += ((f32x4){1.f, 1.f, 1.f, 1.f} - z) * *(const f32x4*)(a.h + (size_t)row * a.ldh + col);
+        *(f32x4*)(a.Y + (size_t)row * a.ldy + col) = hn;
+    } else {  // BMP_EPI_GRU_DRH
+        const f32x4 r = *(const f32x4*)(a.r + (size_t)row * a.ldr + col);
+        const f32x4 h = *(const f32x4*)(a.h + (size_t)row * a.ldh + col);
+        *(f32x4*)(a.Y + (size_t)row * a.ldy + col) = v * h * r * ((f32x4){1.f, 1.f, 1.f, 1.f} - r);
+        f32x4* o = (f32x4*)(a.o1 + (size_t)row * a.ldo1 + col);
+        *o += v * r;
+    }
+}
+// strides and addresses of everything an epilogue touches row by row allow the 16-byte form
+static bool rg_vec_ok(const RGArgs& a, int epi) {
+    auto al = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld & 3) == 0); };
+    if ((a.Nout & 3) != 0 || !al(a.Y, a.ldy)) return false;
+    if (epi == BMP_EPI_GENERIC)
+        return al(a.add, a.ldadd) && al(a.o1, a.ldo1) && (a.split <= 0 || (a.split & 3) == 0) && (((uintptr_t)a.wdeg) & 15) == 0;
+    if (epi == BMP_EPI_GRU_OUT) return al(a.z, a.ldz) && al(a.c_out, a.ldc) && al(a.h, a.ldh);
+    return al(a.r, a.ldr) && al(a.h, a.ldh) && al(a.o1, a.ldo1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -429,6 +493,31 @@ __device__ __forceinline__ void rowgemm_db_body(const RGArgs& a, int bx, int by,
         if (more) store_chunk(buf ^ 1);        // the other buffer: last read in chunk c - 1, every wave is past that barrier
         __syncthreads();
     }
+    if (a.vec_epi) {
+        // The tile crosses to row-major through LDS (free by now: every wave is past the last chunk's barrier): the epilogue's
+        // loads and stores are 16 bytes per lane, 512-byte rows per half wave.  In accumulator layout a wave instruction moves
+        // two 128-byte row pieces; the GRU epilogues' five such accesses per element made them a fifth of the step on the
+        // d = 256 configuration (probe without any epilogue: 8.22 -> 6.23 ms of row GEMMs per C4 step).
+        constexpr int LDT = NT + 4;
+        float* T = lds;                                  // [128][LDT] <= the two staging buffers
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) T[(rb * 32 + bmp_acc_row(reg, lane)) * LDT + wc * 32 + l31] = acc[rb][reg];
+        __syncthreads();
+        const int c4 = tid & 31, col4 = n0 + 4 * c4;
+        if (col4 < a.Nout) {
+            const RGCol4 cc = rg_col4(a, col4);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int lr = (tid >> 5) + 8 * it;
+                const f32x4 v = *(const f32x4*)(T + lr * LDT + 4 * c4);
+                if (LISTED) { if (row0 + lr < count) rg_epilogue4<EPI>(a, cc, rows[lr], col4, v); }
+                else rg_epilogue4<EPI>(a, cc, row0 + lr, col4, v);
+            }
+        }
+        return;
+    }
     const int col = n0 + wc * 32 + l31;
     if (col < a.Nout) {
         const RGCol cc = rg_col(a, col);
@@ -510,7 +599,12 @@ static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
         // round either way, and its duration is one workgroup's latency
         static const int form = getenv("BMP_ROWGEMM_FORM") ? atoi(getenv("BMP_ROWGEMM_FORM")) : 0;    // 1: single-buffered form
         if (n_tiles * ny <= 256) hipLaunchKernelGGL((k_rowgemm<1, 2, 1, EPI>), dim3(2 * n_tiles, ny), dim3(256), 0, st, a);
-        else if (rowgemm_lds_ok(a) && form != 1) hipLaunchKernelGGL((k_rowgemm_db<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
+        else if (rowgemm_lds_ok(a) && form != 1) {
+            static const bool scalar_epi = getenv("BMP_ROWGEMM_SCALAR_EPI") != nullptr;      // A/B: the accumulator-layout epilogue
+            RGArgs b = a;
+            b.vec_epi = !scalar_epi && rg_vec_ok(a, EPI);
+            hipLaunchKernelGGL((k_rowgemm_db<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, b);
+        }
         else if (rowgemm_lds_ok(a)) hipLaunchKernelGGL((k_rowgemm_lds<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_rowgemm<1, 4, 1, EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
     }
@@ -549,7 +643,10 @@ int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st) 
     // (flop accounting: the listed share is not known on the host; the roofline leg's algorithmic figure counts every row)
     const double rows = (double)n_tiles_cap * BMP_R;
     BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * ksum * a.Nout, 4.0 * rows * (ksum + a.Nout), st);
-    hipLaunchKernelGGL(k_rowgemm_db_listed, dim3(n_tiles_cap, (a.Nout + 127) / 128), dim3(256), 0, st, a);
+    static const bool scalar_epi = getenv("BMP_ROWGEMM_SCALAR_EPI") != nullptr;
+    RGArgs b = a;
+    b.vec_epi = !scalar_epi && rg_vec_ok(a, BMP_EPI_GENERIC);
+    hipLaunchKernelGGL(k_rowgemm_db_listed, dim3(n_tiles_cap, (a.Nout + 127) / 128), dim3(256), 0, st, b);
     BMP_LAUNCH_CHECK();
     return 0;
 }

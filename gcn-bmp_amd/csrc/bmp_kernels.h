@@ -47,6 +47,7 @@ struct RGArgs {
     const float* r; int ldr;
     float* c_out; int ldc;
     int first;
+    int vec_epi;                     // set by the launchers (rg_vec_ok): the LDS-staged kernels write the tile row-major, 16 bytes per lane
 };
 
 int bmp_launch_rowgemm(const RGArgs& a, int n_tiles, int epi, hipStream_t st);
