@@ -16,8 +16,10 @@ def _run(tmp_path, form):
     (single-buffered 64-deep chunks, BMP_ROWGEMM_FORM=1) or "direct" (weights straight from L2, BMP_ROWGEMM_DIRECT=1)."""
     out = str(tmp_path / f"{form}.pt")
     env = dict(os.environ)
-    env.pop("BMP_ROWGEMM_DIRECT", None); env.pop("BMP_ROWGEMM_FORM", None)
-    if form == "direct":
+    env.pop("BMP_ROWGEMM_DIRECT", None); env.pop("BMP_ROWGEMM_FORM", None); env.pop("BMP_ROWGEMM_SCALAR_EPI", None)
+    if form == "db_scalar_epilogue":
+        env["BMP_ROWGEMM_SCALAR_EPI"] = "1"
+    elif form == "direct":
         env["BMP_ROWGEMM_DIRECT"] = "1"
     elif form == "lds":
         env["BMP_ROWGEMM_FORM"] = "1"
@@ -35,3 +37,21 @@ def test_lds_forms_equal_direct_form(tmp_path):
                 scale = max(float(y.abs().max()), 1e-6)
                 err = float((x - y).abs().max())
                 assert err <= 2e-5 * scale, f"{form} {key}[{k}]: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_row_major_epilogue_equals_the_accumulator_layout_one(tmp_path):
+    """k_rowgemm_db writes its tile row-major through LDS, 16 bytes per lane (round 4); BMP_ROWGEMM_SCALAR_EPI=1 keeps the
+    accumulator-layout epilogue.  The same products in the same order and the same arithmetic per element: every output of the
+    GRU (both epilogue kinds, first and later call), forward and backward, is IDENTICAL; the message layer's (per-bond-type
+    bias: a sum of four products per element that the compiler contracts into fused multiply-adds differently in the two
+    forms) within 1e-6 of the tensor's scale -- one unit in the last place."""
+    a = _run(tmp_path, "db")
+    b = _run(tmp_path, "db_scalar_epilogue")
+    assert set(a) == set(b)
+    for key in a:
+        for k, (x, y) in enumerate(zip(a[key], b[key])):
+            if key.startswith("gru"):
+                assert torch.equal(x, y), f"{key}[{k}]: max diff {float((x - y).abs().max()):.3e}"
+            else:
+                scale = max(float(y.abs().max()), 1e-6)
+                assert float((x - y).abs().max()) <= 1e-6 * scale, f"{key}[{k}]"
