@@ -244,6 +244,27 @@ __device__ __forceinline__ void rowgemm_body(const RGArgs& a, int bx, int by, fl
         }
     }
 
+    if (a.vec_epi) {
+        // row-major through LDS, 16 bytes per lane (see rowgemm_db_body; the caller's array holds R x max(BMP_LDS_LD, NT + 4) floats)
+        constexpr int LDT = NT + 4, P4 = NT / 4;            // pieces of four columns per row
+        __syncthreads();                                    // every wave is done with the last chunk in LDS
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    lds[((wr * RB + rb) * 32 + bmp_acc_row(reg, lane)) * LDT + (wc * CBW + cb) * 32 + l31] = acc[rb][cb][reg];
+        __syncthreads();
+        const int c4 = tid % P4, col4 = n0 + 4 * c4;
+        if (col4 < a.Nout) {
+            const RGCol4 cc = rg_col4(a, col4);
+#pragma unroll 4
+            for (int lr = tid / P4; lr < R; lr += 256 / P4)
+                rg_epilogue4<EPI>(a, cc, row0 + lr, col4, *(const f32x4*)(&lds[lr * LDT + 4 * c4]));
+        }
+        return;
+    }
     if (wave_active)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -561,7 +582,8 @@ static bool rowgemm_lds_ok(const RGArgs& a) {
 
 template <int WR, int RB, int CBW, int EPI>
 __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[WR * RB * 32 * BMP_LDS_LD];
+    constexpr int NT = (4 / WR) * CBW * 32;
+    __shared__ __attribute__((aligned(16))) float lds[WR * RB * 32 * (NT + 4 > BMP_LDS_LD ? NT + 4 : BMP_LDS_LD)];      // staging | the row-major epilogue's tile
     rowgemm_body<WR, RB, CBW, EPI>(a, blockIdx.x, blockIdx.y, lds);
 }
 
@@ -577,7 +599,7 @@ __global__ __launch_bounds__(256) void k_rowgemm(RGArgs a) {
 #define RGM_MAXP 6
 struct RGMulti { RGArgs p[RGM_MAXP]; int bx0[RGM_MAXP + 1]; int ny[RGM_MAXP]; int thin[RGM_MAXP]; };
 __global__ __launch_bounds__(256) void k_rowgemm_multi(RGMulti m) {
-    __shared__ __attribute__((aligned(16))) float lds[(BMP_R / 2) * BMP_LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[(BMP_R / 2) * (128 + 4)];       // (64-row staging | the row-major epilogue's 64 x 128 tile)
     const int bx = blockIdx.x;
     int p = 0;
 #pragma unroll
@@ -587,8 +609,15 @@ __global__ __launch_bounds__(256) void k_rowgemm_multi(RGMulti m) {
     else rowgemm_body<1, 2, 1, BMP_EPI_GENERIC>(m.p[p], bx - m.bx0[p], blockIdx.y, lds);      // 64-row workgroups: two per tile
 }
 
+static bool rg_scalar_epilogue() {
+    static const bool on = getenv("BMP_ROWGEMM_SCALAR_EPI") != nullptr;      // A/B: the accumulator-layout epilogue everywhere
+    return on;
+}
+
 template <int EPI>
-static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
+static int launch_rowgemm_epi(const RGArgs& a_, int n_tiles, hipStream_t st) {
+    RGArgs a = a_;
+    a.vec_epi = !rg_scalar_epilogue() && rg_vec_ok(a_, EPI);       // (k_rowgemm_lds keeps the accumulator-layout form)
     if (a.Nout <= 32) {
         hipLaunchKernelGGL((k_rowgemm<4, 1, 1, EPI>), dim3(n_tiles, 1), dim3(256), 0, st, a);
     } else if (a.Nout <= 64) {
@@ -599,12 +628,7 @@ static int launch_rowgemm_epi(const RGArgs& a, int n_tiles, hipStream_t st) {
         // round either way, and its duration is one workgroup's latency
         static const int form = getenv("BMP_ROWGEMM_FORM") ? atoi(getenv("BMP_ROWGEMM_FORM")) : 0;    // 1: single-buffered form
         if (n_tiles * ny <= 256) hipLaunchKernelGGL((k_rowgemm<1, 2, 1, EPI>), dim3(2 * n_tiles, ny), dim3(256), 0, st, a);
-        else if (rowgemm_lds_ok(a) && form != 1) {
-            static const bool scalar_epi = getenv("BMP_ROWGEMM_SCALAR_EPI") != nullptr;      // A/B: the accumulator-layout epilogue
-            RGArgs b = a;
-            b.vec_epi = !scalar_epi && rg_vec_ok(a, EPI);
-            hipLaunchKernelGGL((k_rowgemm_db<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, b);
-        }
+        else if (rowgemm_lds_ok(a) && form != 1) hipLaunchKernelGGL((k_rowgemm_db<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
         else if (rowgemm_lds_ok(a)) hipLaunchKernelGGL((k_rowgemm_lds<EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_rowgemm<1, 4, 1, EPI>), dim3(n_tiles, ny), dim3(256), 0, st, a);
     }
@@ -643,9 +667,8 @@ int bmp_launch_rowgemm_listed(const RGArgs& a, int n_tiles_cap, hipStream_t st) 
     // (flop accounting: the listed share is not known on the host; the roofline leg's algorithmic figure counts every row)
     const double rows = (double)n_tiles_cap * BMP_R;
     BmpProfScope prof(BMP_KCLS_ROWGEMM, 2.0 * rows * ksum * a.Nout, 4.0 * rows * (ksum + a.Nout), st);
-    static const bool scalar_epi = getenv("BMP_ROWGEMM_SCALAR_EPI") != nullptr;
     RGArgs b = a;
-    b.vec_epi = !scalar_epi && rg_vec_ok(a, BMP_EPI_GENERIC);
+    b.vec_epi = !rg_scalar_epilogue() && rg_vec_ok(a, BMP_EPI_GENERIC);
     hipLaunchKernelGGL(k_rowgemm_db_listed, dim3(n_tiles_cap, (a.Nout + 127) / 128), dim3(256), 0, st, b);
     BMP_LAUNCH_CHECK();
     return 0;
@@ -687,6 +710,7 @@ int bmp_launch_rowgemm_multi(const RGArgs* a, const int* n_tiles, int n, hipStre
         ++np;
     }
     int blocks = 0;
+    for (int q = 0; q < np; ++q) m.p[q].vec_epi = !rg_scalar_epilogue() && rg_vec_ok(m.p[q], BMP_EPI_GENERIC);
     for (int q = 0; q < np; ++q) { m.bx0[q] = blocks; blocks += 2 * nt_of[q]; }
     for (int q = np; q <= RGM_MAXP; ++q) m.bx0[q] = blocks;
     for (int q = np; q < RGM_MAXP; ++q) m.bx0[q] = 0x7fffffff;      // (the kernel's search never lands behind the last problem)
