@@ -14,7 +14,7 @@
  *     (lock-free, per device: one process may drive several devices, from several host threads);
  *     (ii) A/B switches read once from the environment (BMP_WGRAD_DMA, BMP_WGRAD_XCD,
  *     BMP_STEP_WGRAD_UNFUSED, BMP_ROWGEMM_FORM / _DIRECT: diagnostics of tools/ and tests/,
- *     BMP_ROWGEMM_NO_THIN);
+ *     BMP_ROWGEMM_NO_THIN, BMP_ROWGEMM_SCALAR_EPI);
  *     (iii) the opt-in event timer bmp_prof_*.  None of them changes a result.  The code object
  *     also holds one read-only device array of 128 zero floats (what a listed weight-gradient
  *     problem reads past the end of its list).
